@@ -1,0 +1,1009 @@
+// extern "C" boundary (include/ldpc_hip.h): handles, argument checking, device
+// buffers and kernel launches.  No compute happens on the host here: sampling,
+// syndromes, decoding and failure tests all run in the kernels of kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+#include "host_codes.hpp"
+#include "kernels.hpp"
+
+using namespace ldpc;
+
+// ---------------------------------------------------------------------------
+// error / runtime state
+// ---------------------------------------------------------------------------
+namespace {
+thread_local std::string g_error;
+thread_local hipStream_t g_stream = nullptr;
+thread_local double g_last_ms = 0.0;
+
+int fail(int status, const std::string &msg)
+{
+    g_error = msg;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(LDPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t reserve(size_t want)
+    {
+        if (want <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, want ? want : 1);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// kernel timing on the launch stream
+struct KernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool ok = false;
+    KernelTimer()
+    {
+        ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+        if (ok) (void)hipEventRecord(a, g_stream);
+    }
+    void stop_and_store()
+    {
+        if (!ok) return;
+        (void)hipEventRecord(b, g_stream);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) g_last_ms = ms;
+    }
+    ~KernelTimer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+inline size_t words_for(size_t nbits) { return (nbits + 63) / 64; }
+
+bool valid_probability(double p) { return p >= 0.0 && p <= 1.0; }   // noise/mod.rs:40-46
+
+GapTable make_gap_table(double p)
+{
+    GapTable t;
+    double q = 1.0 - p, qj = 1.0;
+    t.q[0] = 0xFFFFFFFFu;
+    for (int j = 1; j <= 64; j++) {
+        qj = qj * q;
+        double f = std::floor(qj * 4294967296.0);
+        t.q[j] = f >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)f;
+    }
+    t.p_is_zero = p == 0.0;
+    return t;
+}
+
+// strictly ascending, in range (SparseBinVec::new panics otherwise)
+bool valid_positions(const size_t *pos, size_t n, size_t len)
+{
+    for (size_t k = 0; k < n; k++) {
+        if (pos[k] >= len) return false;
+        if (k && pos[k] <= pos[k - 1]) return false;
+    }
+    return true;
+}
+
+std::vector<uint64_t> pack(const size_t *pos, size_t n, size_t len)
+{
+    std::vector<uint64_t> w(std::max<size_t>(words_for(len), 1), 0);
+    for (size_t k = 0; k < n; k++) w[pos[k] >> 6] |= 1ull << (pos[k] & 63);
+    return w;
+}
+
+void unpack(const std::vector<uint64_t> &w, size_t len, size_t *out, size_t *out_n)
+{
+    size_t k = 0;
+    for (size_t i = 0; i < len; i++)
+        if ((w[i >> 6] >> (i & 63)) & 1) out[k++] = i;
+    *out_n = k;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct ldpc_code {
+    LinearCode host;
+    mutable std::mutex mu;
+    mutable bool uploaded = false;
+    mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge;
+    mutable DeviceGraph dg{};
+
+    int ensure_device() const
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (uploaded) return LDPC_OK;
+        const SparseBinMat &h = host.h, &t = host.ht;
+        // slot of bit_adjacencies -> edge index in check-major order
+        std::vector<uint32_t> tedge(t.nnz());
+        {
+            std::vector<uint32_t> fill(t.ptr.begin(), t.ptr.end() - 1);
+            for (uint32_t r = 0; r < h.nrows(); r++)
+                for (uint32_t e = h.ptr[r]; e < h.ptr[r + 1]; e++) tedge[fill[h.idx[e]]++] = e;
+        }
+        auto up = [](DeviceBuffer &b, const std::vector<uint32_t> &v) -> hipError_t {
+            hipError_t e = b.reserve(std::max<size_t>(v.size(), 1) * 4);
+            if (e != hipSuccess) return e;
+            if (v.empty()) return hipSuccess;
+            return hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+        };
+        HIP_TRY(up(d_hptr, h.ptr));
+        HIP_TRY(up(d_hidx, h.idx));
+        HIP_TRY(up(d_tptr, t.ptr));
+        HIP_TRY(up(d_tidx, t.idx));
+        HIP_TRY(up(d_tedge, tedge));
+        dg.n = h.ncols;
+        dg.m = h.nrows();
+        dg.E = h.nnz();
+        dg.max_dc = h.max_row_len();
+        dg.max_dv = t.max_row_len();
+        dg.h_ptr = d_hptr.as<uint32_t>();
+        dg.h_idx = d_hidx.as<uint32_t>();
+        dg.t_ptr = d_tptr.as<uint32_t>();
+        dg.t_idx = d_tidx.as<uint32_t>();
+        dg.t_edge = d_tedge.as<uint32_t>();
+        uploaded = true;
+        return LDPC_OK;
+    }
+};
+
+struct ldpc_css_code {
+    ldpc_code m[4];   // 0 x stabilizers, 1 z stabilizers, 2 x logicals, 3 z logicals
+};
+
+struct ldpc_flip_decoder {
+    ldpc_code code;
+    std::mutex mu;
+    DeviceBuffer counters;
+};
+
+struct ldpc_bp_decoder {
+    ldpc_code code;
+    double p = 0.5;
+    uint32_t max_iter = 0;
+    std::mutex mu;
+    DeviceBuffer counters, workspace;
+    uint32_t groups_allocated = 0;
+};
+
+struct ldpc_css_bp_decoder {
+    ldpc_bp_decoder x;   // BpDecoder on Hx: decodes syndrome.x, corrects the z part
+    ldpc_bp_decoder z;   // BpDecoder on Hz: decodes syndrome.z, corrects the x part
+    ldpc_code lx, lz;
+    std::mutex mu;
+    DeviceBuffer flags, counters;
+};
+
+namespace {
+
+void copy_code(ldpc_code &dst, const LinearCode &src) { dst.host = src; }
+
+ldpc_code *new_code(LinearCode c)
+{
+    ldpc_code *h = new ldpc_code();
+    h->host = std::move(c);
+    return h;
+}
+
+void export_csr(const SparseBinMat &m, size_t *row_ptr, size_t *col_idx)
+{
+    for (size_t i = 0; i < m.ptr.size(); i++) row_ptr[i] = m.ptr[i];
+    for (size_t i = 0; i < m.idx.size(); i++) col_idx[i] = m.idx[i];
+}
+
+// --- device scratch for the single-vector entry points -----------------------
+struct Scratch {
+    DeviceBuffer in, out, aux, aux2;
+};
+
+int read_counters(DeviceBuffer &d, uint64_t *out)
+{
+    unsigned long long tmp[LDPC_COUNTERS];
+    HIP_TRY(hipMemcpyAsync(tmp, d.p, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < LDPC_COUNTERS; i++) out[i] = tmp[i];
+    return LDPC_OK;
+}
+
+int zero_counters(DeviceBuffer &d)
+{
+    HIP_TRY(d.reserve(sizeof(unsigned long long) * LDPC_COUNTERS));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * LDPC_COUNTERS, g_stream));
+    return LDPC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// flip driver
+// ---------------------------------------------------------------------------
+int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
+{
+    int st = dec->code.ensure_device();
+    if (st) return st;
+    std::lock_guard<std::mutex> lock(dec->mu);
+    st = zero_counters(dec->counters);
+    if (st) return st;
+    a.counters = dec->counters.as<unsigned long long>();
+    const DeviceGraph &g = dec->code.dg;
+    size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
+    if (33 * 8 + per_wave > 160 * 1024)
+        return fail(LDPC_ERR_CAPACITY, "flip decoder: per-shot state of " + std::to_string(per_wave) +
+                                           " bytes does not fit the 160 KiB LDS of a CU");
+    KernelTimer timer;
+    HIP_TRY(launch_flip(g, a, g_stream));
+    timer.stop_and_store();
+    if (counters_out) return read_counters(dec->counters, counters_out);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return LDPC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BP driver
+// ---------------------------------------------------------------------------
+struct BpRun {
+    int source = SRC_BSC, test = TEST_NONE, xor_input = 0;
+    uint32_t fail_bit = 1;
+    GapTable gap{};
+    uint64_t seed = 0, first_shot = 0, n_shots = 0;
+    const uint64_t *words_in = nullptr, *synd_in = nullptr;
+    uint64_t *corr_out = nullptr;
+    uint32_t *iters_out = nullptr;
+    double *post_out = nullptr;
+    uint8_t *failed_out = nullptr;
+    const ldpc_code *logicals = nullptr;
+};
+
+int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool time_it = true)
+{
+    int st = dec->code.ensure_device();
+    if (st) return st;
+    if (r.logicals && (st = r.logicals->ensure_device())) return st;
+    std::lock_guard<std::mutex> lock(dec->mu);
+    st = zero_counters(dec->counters);
+    if (st) return st;
+    const DeviceGraph &g = dec->code.dg;
+    if (r.n_shots == 0) {
+        if (counters_out) return read_counters(dec->counters, counters_out);
+        return LDPC_OK;
+    }
+    // shot groups: one wave of 64 slots each; bounded by memory and by what fills the chip
+    size_t per_group = bp_workspace_bytes_per_group(g);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.6), (size_t)96 << 30);
+    uint64_t max_groups = std::min<uint64_t>(4096, budget / std::max<size_t>(per_group, 1));
+    if (max_groups == 0)
+        return fail(LDPC_ERR_CAPACITY, "bp decoder: one shot group needs " + std::to_string(per_group) +
+                                           " bytes of message storage, more than the device can give");
+    uint64_t groups = std::min<uint64_t>(max_groups, (r.n_shots + 63) / 64);
+    groups = std::max<uint64_t>(groups, 1);
+    uint64_t quota = (r.n_shots + groups - 1) / groups;
+    HIP_TRY(dec->workspace.reserve(per_group * groups));
+
+    BpArgs a{};
+    a.source = r.source;
+    a.test = r.test;
+    a.xor_input = r.xor_input;
+    a.max_iter = dec->max_iter;
+    a.fail_bit = r.fail_bit;
+    a.prior = std::log((1.0 - dec->p) / dec->p);   // belief_propagation.rs:38
+    a.seed = r.seed;
+    a.first_shot = r.first_shot;
+    a.n_shots = r.n_shots;
+    a.quota = quota;
+    a.words_in = r.words_in;
+    a.synd_in = r.synd_in;
+    a.corr_out = r.corr_out;
+    a.iters_out = r.iters_out;
+    a.post_out = r.post_out;
+    a.failed_out = r.failed_out;
+    a.counters = dec->counters.as<unsigned long long>();
+    if (r.logicals) {
+        a.l_rows = r.logicals->dg.m;
+        a.l_ptr = r.logicals->dg.h_ptr;
+        a.l_idx = r.logicals->dg.h_idx;
+    }
+    size_t Wn = words_for(g.n);
+    char *base = dec->workspace.as<char>();
+    a.msg = (double *)base;
+    base += groups * 2 * (size_t)g.E * 64 * sizeof(double);
+    a.ew = (uint64_t *)base;
+    base += groups * Wn * 64 * 8;
+    a.dw = (uint64_t *)base;
+    base += groups * Wn * 64 * 8;
+    a.dsl = (uint64_t *)base;
+    base += groups * (size_t)g.n * 8;
+    a.ssl = (uint64_t *)base;
+    a.gap = r.gap;
+
+    std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);
+    HIP_TRY(launch_bp(g, a, (uint32_t)groups, g_stream));
+    if (timer) timer->stop_and_store();
+    if (counters_out) return read_counters(dec->counters, counters_out);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return LDPC_OK;
+}
+
+int init_bp(ldpc_bp_decoder *d, const LinearCode &code, double p, size_t max_iterations)
+{
+    if (!valid_probability(p)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (max_iterations > 0xFFFFFFFFull) return fail(LDPC_ERR_BAD_ARG, "max_iterations too large");
+    copy_code(d->code, code);
+    d->p = p;
+    d->max_iter = (uint32_t)max_iterations;
+    return LDPC_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C"
+// ===========================================================================
+extern "C" {
+
+const char *ldpc_last_error(void) { return g_error.c_str(); }
+
+int ldpc_device_count(int *count)
+{
+    if (!count) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(LDPC_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return LDPC_OK;
+}
+
+int ldpc_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return LDPC_OK;
+}
+
+int ldpc_set_stream(void *hip_stream)
+{
+    g_stream = (hipStream_t)hip_stream;
+    return LDPC_OK;
+}
+
+double ldpc_last_kernel_ms(void) { return g_last_ms; }
+
+// ---- LinearCode -----------------------------------------------------------
+int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
+{
+    if (!out || (!row_ptr && n_checks)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (n_bits >= 0xFFFFFFFFull || n_checks >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "dimension exceeds 32 bits");
+    std::vector<std::vector<uint32_t>> rows(n_checks);
+    if (n_checks) {
+        if (row_ptr[0] != 0) return fail(LDPC_ERR_BAD_ARG, "row_ptr[0] must be 0");
+        if (row_ptr[n_checks] >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "too many edges");
+        for (size_t r = 0; r < n_checks; r++) {
+            if (row_ptr[r + 1] < row_ptr[r]) return fail(LDPC_ERR_BAD_ARG, "row_ptr must be non-decreasing");
+            for (size_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+                if (col_idx[e] >= n_bits) return fail(LDPC_ERR_BAD_ARG, "column index out of bound");
+                rows[r].push_back((uint32_t)col_idx[e]);
+            }
+        }
+    }
+    SparseBinMat h;
+    std::string err;
+    if (!SparseBinMat::from_rows((uint32_t)n_bits, rows, h, err)) return fail(LDPC_ERR_BAD_ARG, err);
+    *out = new_code(make_code(std::move(h)));
+    return LDPC_OK;
+}
+
+int ldpc_code_hamming(ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    *out = new_code(hamming_code());
+    return LDPC_OK;
+}
+
+int ldpc_code_repetition(size_t length, ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (length == 0 || length >= 0xFFFFFFFFull) return fail(LDPC_ERR_BAD_ARG, "invalid repetition code length");
+    *out = new_code(repetition_code((uint32_t)length));
+    return LDPC_OK;
+}
+
+int ldpc_code_random_regular(size_t n_bits, size_t n_checks, size_t bit_degree, size_t check_degree, uint64_t seed,
+                             ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    LinearCode c;
+    if (n_bits >= 0xFFFFFFFFull || n_checks >= 0xFFFFFFFFull || bit_degree >= 0xFFFFFFFFull ||
+        check_degree >= 0xFFFFFFFFull ||
+        !random_regular_code((uint32_t)n_bits, (uint32_t)n_checks, (uint32_t)bit_degree, (uint32_t)check_degree, seed, c))
+        return fail(LDPC_ERR_SAMPLING, "can't generate a regular code with " + std::to_string(n_bits) +
+                                           " bits of degree " + std::to_string(bit_degree) + " and " +
+                                           std::to_string(n_checks) + " checks of degree " +
+                                           std::to_string(check_degree));   // random.rs:97-104
+    *out = new_code(std::move(c));
+    return LDPC_OK;
+}
+
+size_t ldpc_code_len(const ldpc_code *code) { return code ? code->host.len() : 0; }
+size_t ldpc_code_num_checks(const ldpc_code *code) { return code ? code->host.num_checks() : 0; }
+size_t ldpc_code_num_edges(const ldpc_code *code) { return code ? code->host.h.nnz() : 0; }
+
+int ldpc_code_parity_check_matrix(const ldpc_code *code, size_t *row_ptr, size_t *col_idx)
+{
+    if (!code || !row_ptr || (!col_idx && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    export_csr(code->host.h, row_ptr, col_idx);
+    return LDPC_OK;
+}
+
+int ldpc_code_bit_adjacencies(const ldpc_code *code, size_t *row_ptr, size_t *col_idx)
+{
+    if (!code || !row_ptr || (!col_idx && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    export_csr(code->host.ht, row_ptr, col_idx);
+    return LDPC_OK;
+}
+
+int ldpc_code_edges(const ldpc_code *code, size_t *bits, size_t *checks)
+{
+    if (!code || ((!bits || !checks) && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    const SparseBinMat &h = code->host.h;
+    for (uint32_t r = 0; r < h.nrows(); r++)
+        for (uint32_t e = h.ptr[r]; e < h.ptr[r + 1]; e++) {
+            bits[e] = h.idx[e];
+            checks[e] = r;
+        }
+    return LDPC_OK;
+}
+
+int ldpc_code_syndrome_batch(const ldpc_code *code, size_t n_shots, const uint64_t *d_words, uint64_t *d_syndromes)
+{
+    if (!code || (n_shots && (!d_words || !d_syndromes))) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    int st = code->ensure_device();
+    if (st) return st;
+    KernelTimer timer;
+    HIP_TRY(launch_syndrome(code->dg, n_shots, d_words, d_syndromes, g_stream));
+    timer.stop_and_store();
+    return LDPC_OK;
+}
+
+int ldpc_code_syndrome_of(const ldpc_code *code, size_t len, const size_t *positions, size_t n_positions,
+                          size_t *out_positions, size_t *out_n)
+{
+    if (!code || !out_n || (n_positions && !positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (len != code->host.len())
+        return fail(LDPC_ERR_LENGTH_MISMATCH, "message of length " + std::to_string(len) +
+                                                  " is invalid for code with length " +
+                                                  std::to_string(code->host.len()));   // mod.rs:397-403
+    if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
+    size_t m = code->host.num_checks();
+    std::vector<uint64_t> in = pack(positions, n_positions, len), out(std::max<size_t>(words_for(m), 1), 0);
+    DeviceBuffer din, dout;
+    HIP_TRY(din.reserve(in.size() * 8));
+    HIP_TRY(dout.reserve(out.size() * 8));
+    HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
+    int st = ldpc_code_syndrome_batch(code, 1, din.as<uint64_t>(), dout.as<uint64_t>());
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(out.data(), dout.p, out.size() * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (!m) out[0] = 0;
+    size_t k = 0;
+    if (out_positions) unpack(out, m, out_positions, &k);
+    else
+        for (size_t i = 0; i < m; i++) k += (out[i >> 6] >> (i & 63)) & 1;
+    *out_n = k;
+    return LDPC_OK;
+}
+
+int ldpc_code_has_codeword(const ldpc_code *code, size_t len, const size_t *positions, size_t n_positions, int *out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t k = 0;
+    int st = ldpc_code_syndrome_of(code, len, positions, n_positions, nullptr, &k);
+    if (st) return st;
+    *out = k == 0;   // mod.rs:435
+    return LDPC_OK;
+}
+
+void ldpc_code_destroy(ldpc_code *code) { delete code; }
+
+// ---- noise ----------------------------------------------------------------
+int ldpc_bsc_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                          uint64_t *d_words)
+{
+    if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
+    if (n_shots && len && !d_words) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    KernelTimer timer;
+    HIP_TRY(launch_sample_bsc(make_gap_table(probability), (uint32_t)len, seed, first_shot, n_shots, d_words, g_stream));
+    timer.stop_and_store();
+    return LDPC_OK;
+}
+
+int ldpc_depolarizing_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                                   uint64_t *d_x_words, uint64_t *d_z_words)
+{
+    if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
+    if (n_shots && len && (!d_x_words || !d_z_words)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    KernelTimer timer;
+    HIP_TRY(launch_sample_depol(make_gap_table(probability), (uint32_t)len, seed, first_shot, n_shots, d_x_words,
+                                d_z_words, g_stream));
+    timer.stop_and_store();
+    return LDPC_OK;
+}
+
+int ldpc_bsc_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot, size_t *out_positions,
+                                    size_t *out_n)
+{
+    if (!out_n || (len && !out_positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    std::vector<uint64_t> w(std::max<size_t>(words_for(len), 1), 0);
+    DeviceBuffer d;
+    HIP_TRY(d.reserve(w.size() * 8));
+    int st = ldpc_bsc_sample_batch(probability, len, seed, shot, 1, d.as<uint64_t>());
+    if (st) return st;
+    if (len) HIP_TRY(hipMemcpyAsync(w.data(), d.p, words_for(len) * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    unpack(w, len, out_positions, out_n);
+    return LDPC_OK;
+}
+
+int ldpc_depolarizing_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
+                                             size_t *out_positions, uint8_t *out_paulis, size_t *out_n)
+{
+    if (!out_n || (len && (!out_positions || !out_paulis))) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t W = std::max<size_t>(words_for(len), 1);
+    std::vector<uint64_t> x(W, 0), z(W, 0);
+    DeviceBuffer dx, dz;
+    HIP_TRY(dx.reserve(W * 8));
+    HIP_TRY(dz.reserve(W * 8));
+    int st = ldpc_depolarizing_sample_batch(probability, len, seed, shot, 1, dx.as<uint64_t>(), dz.as<uint64_t>());
+    if (st) return st;
+    if (len) {
+        HIP_TRY(hipMemcpyAsync(x.data(), dx.p, words_for(len) * 8, hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(z.data(), dz.p, words_for(len) * 8, hipMemcpyDeviceToHost, g_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    size_t k = 0;
+    for (size_t i = 0; i < len; i++) {
+        int bx = (x[i >> 6] >> (i & 63)) & 1, bz = (z[i >> 6] >> (i & 63)) & 1;
+        if (bx || bz) {
+            out_positions[k] = i;
+            out_paulis[k] = (uint8_t)(bx && bz ? 2 : (bx ? 1 : 3));
+            k++;
+        }
+    }
+    *out_n = k;
+    return LDPC_OK;
+}
+
+// ---- FlipDecoder ----------------------------------------------------------
+int ldpc_flip_create(const ldpc_code *code, ldpc_flip_decoder **out)
+{
+    if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    ldpc_flip_decoder *d = new ldpc_flip_decoder();
+    copy_code(d->code, code->host);
+    *out = d;
+    return LDPC_OK;
+}
+
+int ldpc_flip_decode_batch(ldpc_flip_decoder *dec, size_t n_shots, const uint64_t *d_words_in, uint64_t *d_words_out,
+                           uint64_t *d_syndromes_out, uint32_t *d_flips_out)
+{
+    if (!dec || (n_shots && !d_words_in)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    FlipArgs a{};
+    a.source = SRC_WORDS;
+    a.n_shots = n_shots;
+    a.words_in = d_words_in;
+    a.words_out = d_words_out;
+    a.synd_out = d_syndromes_out;
+    a.flips_out = d_flips_out;
+    a.gap = make_gap_table(0.0);
+    return run_flip(dec, a, nullptr);
+}
+
+int ldpc_flip_decode(ldpc_flip_decoder *dec, size_t len, const size_t *positions, size_t n_positions,
+                     size_t *out_positions, size_t *out_n)
+{
+    if (!dec || !out_n || (n_positions && !positions) || (len && !out_positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (len != dec->code.host.len())
+        return fail(LDPC_ERR_LENGTH_MISMATCH, "message of length " + std::to_string(len) +
+                                                  " is invalid for code with length " +
+                                                  std::to_string(dec->code.host.len()));
+    if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
+    std::vector<uint64_t> in = pack(positions, n_positions, len), out(in.size(), 0);
+    DeviceBuffer din, dout;
+    HIP_TRY(din.reserve(in.size() * 8));
+    HIP_TRY(dout.reserve(in.size() * 8));
+    HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
+    int st = ldpc_flip_decode_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr, nullptr);
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(out.data(), dout.p, in.size() * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (!len) out[0] = 0;
+    unpack(out, len, out_positions, out_n);
+    return LDPC_OK;
+}
+
+int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                     uint64_t counters[LDPC_COUNTERS], uint64_t *d_errors_out, uint64_t *d_syndromes_out,
+                     uint64_t *d_words_out)
+{
+    if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    FlipArgs a{};
+    a.source = SRC_BSC;
+    a.seed = seed;
+    a.first_shot = first_shot;
+    a.n_shots = n_shots;
+    a.errors_out = d_errors_out;
+    a.synd_out = d_syndromes_out;
+    a.words_out = d_words_out;
+    a.gap = make_gap_table(probability);
+    return run_flip(dec, a, counters);
+}
+
+void ldpc_flip_destroy(ldpc_flip_decoder *dec) { delete dec; }
+
+// ---- BpDecoder ------------------------------------------------------------
+int ldpc_bp_create(const ldpc_code *code, double probability, size_t max_iterations, ldpc_bp_decoder **out)
+{
+    if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    std::unique_ptr<ldpc_bp_decoder> d(new ldpc_bp_decoder());
+    int st = init_bp(d.get(), code->host, probability, max_iterations);
+    if (st) return st;
+    *out = d.release();
+    return LDPC_OK;
+}
+
+int ldpc_bp_correction_for_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_syndromes,
+                                 uint64_t *d_corrections_out, uint32_t *d_iterations_out, double *d_posteriors_out)
+{
+    if (!dec || (n_shots && !d_syndromes)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    BpRun r;
+    r.source = SRC_SYNDROMES;
+    r.test = TEST_NONE;
+    r.n_shots = n_shots;
+    r.synd_in = d_syndromes;
+    r.corr_out = d_corrections_out;
+    r.iters_out = d_iterations_out;
+    r.post_out = d_posteriors_out;
+    r.gap = make_gap_table(0.0);
+    return run_bp(dec, r, nullptr);
+}
+
+int ldpc_bp_decode_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_words_in, uint64_t *d_words_out,
+                         uint32_t *d_iterations_out)
+{
+    if (!dec || (n_shots && !d_words_in)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    BpRun r;
+    r.source = SRC_WORDS;
+    r.test = TEST_NONE;
+    r.xor_input = 1;
+    r.n_shots = n_shots;
+    r.words_in = d_words_in;
+    r.corr_out = d_words_out;
+    r.iters_out = d_iterations_out;
+    r.gap = make_gap_table(0.0);
+    return run_bp(dec, r, nullptr);
+}
+
+static int bp_single(ldpc_bp_decoder *dec, bool is_syndrome, size_t len, const size_t *positions, size_t n_positions,
+                     size_t *out_positions, size_t *out_n)
+{
+    if (!dec || !out_n || (n_positions && !positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t n = dec->code.host.len(), m = dec->code.host.num_checks();
+    size_t expect = is_syndrome ? m : n;
+    if (len != expect)
+        return fail(LDPC_ERR_LENGTH_MISMATCH, std::string(is_syndrome ? "syndrome" : "message") + " of length " +
+                                                  std::to_string(len) + " is invalid for a decoder expecting " +
+                                                  std::to_string(expect));
+    if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
+    if (n && !out_positions) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    std::vector<uint64_t> in = pack(positions, n_positions, len), out(std::max<size_t>(words_for(n), 1), 0);
+    DeviceBuffer din, dout;
+    HIP_TRY(din.reserve(in.size() * 8));
+    HIP_TRY(dout.reserve(out.size() * 8));
+    HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
+    int st = is_syndrome
+                 ? ldpc_bp_correction_for_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr, nullptr)
+                 : ldpc_bp_decode_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr);
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(out.data(), dout.p, out.size() * 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (!n) out[0] = 0;
+    unpack(out, n, out_positions, out_n);
+    return LDPC_OK;
+}
+
+int ldpc_bp_correction_for(ldpc_bp_decoder *dec, size_t syndrome_len, const size_t *syndrome_positions,
+                           size_t n_positions, size_t *out_positions, size_t *out_n)
+{
+    return bp_single(dec, true, syndrome_len, syndrome_positions, n_positions, out_positions, out_n);
+}
+
+int ldpc_bp_decode(ldpc_bp_decoder *dec, size_t len, const size_t *positions, size_t n_positions, size_t *out_positions,
+                   size_t *out_n)
+{
+    return bp_single(dec, false, len, positions, n_positions, out_positions, out_n);
+}
+
+int ldpc_bp_mc_run(ldpc_bp_decoder *dec, double noise_probability, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                   uint64_t counters[LDPC_COUNTERS], uint8_t *d_failed_out)
+{
+    if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    BpRun r;
+    r.source = SRC_BSC;
+    r.test = TEST_RESIDUAL;
+    r.seed = seed;
+    r.first_shot = first_shot;
+    r.n_shots = n_shots;
+    r.failed_out = d_failed_out;
+    r.fail_bit = 1;
+    r.gap = make_gap_table(noise_probability);
+    if (d_failed_out && n_shots) HIP_TRY(hipMemsetAsync(d_failed_out, 0, n_shots, g_stream));
+    return run_bp(dec, r, counters);
+}
+
+void ldpc_bp_destroy(ldpc_bp_decoder *dec) { delete dec; }
+
+// ---- CssCode --------------------------------------------------------------
+static ldpc_css_code *new_css(const CssCode &c)
+{
+    ldpc_css_code *h = new ldpc_css_code();
+    h->m[0].host = c.hx;
+    h->m[1].host = c.hz;
+    h->m[2].host = c.lx;
+    h->m[3].host = c.lz;
+    return h;
+}
+
+int ldpc_css_create(const ldpc_code *x_code, const ldpc_code *z_code, ldpc_css_code **out)
+{
+    if (!x_code || !z_code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    CssCode c;
+    int e = css_try_new(x_code->host, z_code->host, c);
+    if (e == 1)
+        return fail(LDPC_ERR_CSS, "different x and z lengths: " + std::to_string(x_code->host.len()) + " & " +
+                                      std::to_string(z_code->host.len()));   // css/mod.rs:375-376
+    if (e == 2) return fail(LDPC_ERR_CSS, "codes are not orthogonal");       // css/mod.rs:378
+    *out = new_css(c);
+    return LDPC_OK;
+}
+
+int ldpc_css_create_with_logicals(const ldpc_code *x_stabs, const ldpc_code *z_stabs, const ldpc_code *x_logicals,
+                                  const ldpc_code *z_logicals, ldpc_css_code **out)
+{
+    if (!x_stabs || !z_stabs || !x_logicals || !z_logicals || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t n = x_stabs->host.len();
+    if (z_stabs->host.len() != n || x_logicals->host.len() != n || z_logicals->host.len() != n)
+        return fail(LDPC_ERR_CSS, "different x and z lengths");
+    CssCode c;
+    c.hx = x_stabs->host;
+    c.hz = z_stabs->host;
+    c.lx = x_logicals->host;
+    c.lz = z_logicals->host;
+    *out = new_css(c);
+    return LDPC_OK;
+}
+
+int ldpc_css_shor(ldpc_css_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    std::string err;
+    SparseBinMat hx, hz, lx, lz;
+    SparseBinMat::from_rows(9, {{0, 1, 2, 3, 4, 5}, {3, 4, 5, 6, 7, 8}}, hx, err);
+    SparseBinMat::from_rows(9, {{0, 1}, {1, 2}, {3, 4}, {4, 5}, {6, 7}, {7, 8}}, hz, err);
+    SparseBinMat::from_rows(9, {{0, 1, 2}}, lx, err);
+    SparseBinMat::from_rows(9, {{0, 3, 6}}, lz, err);
+    CssCode c;
+    c.hx = make_code(hx);
+    c.hz = make_code(hz);
+    c.lx = make_code(lx);
+    c.lz = make_code(lz);
+    *out = new_css(c);
+    return LDPC_OK;
+}
+
+int ldpc_css_steane(ldpc_css_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    CssCode c;
+    LinearCode h = hamming_code();
+    if (css_try_new(h, h, c)) return fail(LDPC_ERR_CSS, "codes are not orthogonal");
+    *out = new_css(c);
+    return LDPC_OK;
+}
+
+static int hgp(const LinearCode &a, const LinearCode &b, ldpc_css_code **out)
+{
+    uint64_t nq = (uint64_t)a.len() * b.len() + (uint64_t)a.num_checks() * b.num_checks();
+    uint64_t nnz = (uint64_t)a.len() * b.h.nnz() + (uint64_t)a.h.nnz() * b.num_checks();
+    if (nq > 200000 || nnz > 50000000ull)
+        return fail(LDPC_ERR_CAPACITY, "hypergraph product too large for the host-side logical-operator algebra");
+    CssCode c;
+    LinearCode xc = make_code(hypergraph_product_x_checks(a, b)), zc = make_code(hypergraph_product_z_checks(a, b));
+    int e = css_try_new(xc, zc, c);
+    if (e) return fail(LDPC_ERR_CSS, e == 1 ? "different x and z lengths" : "codes are not orthogonal");
+    *out = new_css(c);
+    return LDPC_OK;
+}
+
+int ldpc_css_hypergraph_product(const ldpc_code *first, const ldpc_code *second, ldpc_css_code **out)
+{
+    if (!first || !second || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    return hgp(first->host, second->host, out);
+}
+
+int ldpc_css_toric(size_t distance, ldpc_css_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (distance < 2 || distance > 400) return fail(LDPC_ERR_BAD_ARG, "invalid toric code distance");
+    std::vector<std::vector<uint32_t>> rows;                      // css/mod.rs:85-88
+    for (uint32_t c = 0; c + 1 < distance; c++) rows.push_back({c, c + 1});
+    rows.push_back({0, (uint32_t)distance - 1});
+    SparseBinMat h;
+    std::string err;
+    if (!SparseBinMat::from_rows((uint32_t)distance, rows, h, err)) return fail(LDPC_ERR_BAD_ARG, err);
+    LinearCode code = make_code(h);
+    return hgp(code, code, out);
+}
+
+size_t ldpc_css_len(const ldpc_css_code *css) { return css ? css->m[0].host.len() : 0; }
+
+const ldpc_code *ldpc_css_matrix(const ldpc_css_code *css, int which)
+{
+    if (!css || which < 0 || which > 3) return nullptr;
+    return &css->m[which];
+}
+
+int ldpc_css_syndrome_of(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x, const size_t *z_part,
+                         size_t n_z, size_t *out_sx, size_t *out_n_sx, size_t *out_sz, size_t *out_n_sz)
+{
+    if (!css || !out_n_sx || !out_n_sz) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    // css/mod.rs:200-205: stabilizers.pair(operator.swap_xz()): Hx * z_part, Hz * x_part
+    int st = ldpc_code_syndrome_of(&css->m[0], len, z_part, n_z, out_sx, out_n_sx);
+    if (st) return st;
+    return ldpc_code_syndrome_of(&css->m[1], len, x_part, n_x, out_sz, out_n_sz);
+}
+
+int ldpc_css_has_logical(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x, const size_t *z_part,
+                         size_t n_z, int *out)
+{
+    if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t a = 0, b = 0;
+    int st = ldpc_css_syndrome_of(css, len, x_part, n_x, z_part, n_z, nullptr, &a, nullptr, &b);
+    if (st) return st;
+    *out = (a == 0 && b == 0);   // css.rs:137-139 is_trivial
+    return LDPC_OK;
+}
+
+int ldpc_css_has_stabilizer(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x,
+                            const size_t *z_part, size_t n_z, int *out)
+{
+    if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    int logical = 0;
+    int st = ldpc_css_has_logical(css, len, x_part, n_x, z_part, n_z, &logical);
+    if (st) return st;
+    // css/mod.rs:249-251: every logical generator commutes with the operator:
+    // X-type rows of lx against the z part, Z-type rows of lz against the x part
+    size_t a = 0, b = 0;
+    st = ldpc_code_syndrome_of(&css->m[2], len, z_part, n_z, nullptr, &a);
+    if (st) return st;
+    st = ldpc_code_syndrome_of(&css->m[3], len, x_part, n_x, nullptr, &b);
+    if (st) return st;
+    *out = logical && a == 0 && b == 0;
+    return LDPC_OK;
+}
+
+void ldpc_css_destroy(ldpc_css_code *css) { delete css; }
+
+// ---- CssDecoder<BpDecoder> -------------------------------------------------
+int ldpc_css_bp_create(const ldpc_css_code *css, double probability, size_t max_iterations, ldpc_css_bp_decoder **out)
+{
+    if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    std::unique_ptr<ldpc_css_bp_decoder> d(new ldpc_css_bp_decoder());
+    int st = init_bp(&d->x, css->m[0].host, probability, max_iterations);   // css_decoding.rs:42
+    if (st) return st;
+    st = init_bp(&d->z, css->m[1].host, probability, max_iterations);       // css_decoding.rs:43
+    if (st) return st;
+    copy_code(d->lx, css->m[2].host);
+    copy_code(d->lz, css->m[3].host);
+    *out = d.release();
+    return LDPC_OK;
+}
+
+int ldpc_css_bp_correction_for(ldpc_css_bp_decoder *dec, const size_t *sx, size_t n_sx, const size_t *sz, size_t n_sz,
+                               size_t *out_cx, size_t *out_n_cx, size_t *out_cz, size_t *out_n_cz)
+{
+    if (!dec) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    // decoders/css.rs:10-15: pair(x decoder, syndrome.x), pair(z decoder, syndrome.z), then swap_xz
+    int st = ldpc_bp_correction_for(&dec->x, dec->x.code.host.num_checks(), sx, n_sx, out_cz, out_n_cz);
+    if (st) return st;
+    return ldpc_bp_correction_for(&dec->z, dec->z.code.host.num_checks(), sz, n_sz, out_cx, out_n_cx);
+}
+
+int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint64_t seed, uint64_t first_shot,
+                       size_t n_shots, uint64_t counters[LDPC_COUNTERS])
+{
+    if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    std::lock_guard<std::mutex> lock(dec->mu);
+    for (int i = 0; i < LDPC_COUNTERS; i++) counters[i] = 0;
+    GapTable gap = make_gap_table(noise_probability);
+    const size_t chunk_max = (size_t)1 << 28;
+    double ms_total = 0.0;
+    for (size_t done = 0; done < n_shots;) {
+        size_t chunk = std::min(chunk_max, n_shots - done);
+        HIP_TRY(dec->flags.reserve(chunk));
+        HIP_TRY(hipMemsetAsync(dec->flags.p, 0, chunk, g_stream));
+        uint64_t cx[LDPC_COUNTERS], cz[LDPC_COUNTERS], cf[LDPC_COUNTERS];
+        BpRun r;
+        r.test = TEST_LOGICAL;
+        r.seed = seed;
+        r.first_shot = first_shot + done;
+        r.n_shots = chunk;
+        r.failed_out = dec->flags.as<uint8_t>();
+        r.gap = gap;
+        // x part of the error: syndrome.z = Hz * e_x, decoded by the z decoder (BP on Hz);
+        // the residual's x part must commute with the Z-type logicals (rows of lz)
+        r.source = SRC_DEPOL_X;
+        r.fail_bit = 1;
+        r.logicals = &dec->lz;
+        int st = run_bp(&dec->z, r, cx);
+        if (st) return st;
+        ms_total += g_last_ms;
+        // z part: syndrome.x = Hx * e_z, decoded by the x decoder (BP on Hx), logicals lx
+        r.source = SRC_DEPOL_Z;
+        r.fail_bit = 2;
+        r.logicals = &dec->lx;
+        st = run_bp(&dec->x, r, cz);
+        if (st) return st;
+        ms_total += g_last_ms;
+        st = zero_counters(dec->counters);
+        if (st) return st;
+        HIP_TRY(launch_count_flags(dec->flags.as<uint8_t>(), chunk, dec->counters.as<unsigned long long>(), g_stream));
+        st = read_counters(dec->counters, cf);
+        if (st) return st;
+        counters[LDPC_CNT_SHOTS] += chunk;
+        counters[LDPC_CNT_FAILURES] += cf[LDPC_CNT_FAILURES];
+        counters[LDPC_CNT_XFAIL] += cf[LDPC_CNT_XFAIL];
+        counters[LDPC_CNT_ZFAIL] += cf[LDPC_CNT_ZFAIL];
+        counters[LDPC_CNT_WORK] += cx[LDPC_CNT_WORK] + cz[LDPC_CNT_WORK];
+        counters[LDPC_CNT_CAPPED] += cx[LDPC_CNT_CAPPED] + cz[LDPC_CNT_CAPPED];
+        done += chunk;
+    }
+    g_last_ms = ms_total;
+    return LDPC_OK;
+}
+
+void ldpc_css_bp_destroy(ldpc_css_bp_decoder *dec) { delete dec; }
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// Shared device-side definitions: graph layout in HBM, Philox4x32-10 and the
+// noise specification (DESIGN.md "Noise specification").
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ldpc {
+
+// Tanner graph in HBM, CSR both ways, u32 indices.  Edge order is the
+// reference's Edges order (edges.rs:23-29): check-major, bits ascending.
+struct DeviceGraph {
+    uint32_t n;             // bits
+    uint32_t m;             // checks
+    uint32_t E;             // edges
+    uint32_t max_dv;        // largest bit degree
+    uint32_t max_dc;        // largest check degree
+    const uint32_t *h_ptr;  // [m+1]  check -> first edge
+    const uint32_t *h_idx;  // [E]    edge  -> bit
+    const uint32_t *t_ptr;  // [n+1]  bit   -> first slot of bit_adjacencies
+    const uint32_t *t_idx;  // [E]    slot  -> check (ascending inside a bit)
+    const uint32_t *t_edge; // [E]    slot  -> edge index in check-major order
+};
+
+// Geometric gap table of a channel: P(gap >= j) = q[j] / 2^32, j = 1..64.
+struct GapTable {
+    uint32_t q[65];
+    uint32_t p_is_zero;
+};
+
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#ifdef __HIPCC__
+// Draw stream of one (shot, word): Philox counter (shot_lo, shot_hi, word, block),
+// key = seed; 32-bit draws are consumed in order x, y, z, w of successive blocks.
+struct DrawStream {
+    uint32_t s_lo, s_hi, word, block, k0, k1;
+    uint32_t buf[4];
+    int have;
+    __device__ void init(uint64_t seed, uint64_t shot, uint32_t w)
+    {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        s_lo = (uint32_t)shot; s_hi = (uint32_t)(shot >> 32);
+        word = w; block = 0; have = 0;
+    }
+    __device__ uint32_t draw()
+    {
+        if (have == 0) {
+            philox4x32_10(s_lo, s_hi, word, block, k0, k1, buf);
+            block++;
+            have = 4;
+        }
+        uint32_t i = 4 - have;
+        have--;
+        // select without dynamic register indexing
+        return i == 0 ? buf[0] : (i == 1 ? buf[1] : (i == 2 ? buf[2] : buf[3]));
+    }
+};
+
+// gap(u) = #{ j in 1..64 : u < q[j] }, q non-increasing.  `q` may live in LDS or
+// global memory.
+__device__ inline uint32_t gap_of(const uint32_t *q, uint32_t u)
+{
+    uint32_t g = 0;
+#pragma unroll
+    for (uint32_t step = 32; step >= 1; step >>= 1)
+        if (u < q[g + step]) g += step;
+    if (g == 63 && u < q[64]) g = 64;
+    return g;
+}
+
+// One 64-bit word of a BSC sample (binary_symmetric_channel.rs:35-43 distribution).
+__device__ inline uint64_t bsc_word(const uint32_t *q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
+                                    uint32_t nbits)
+{
+    if (p_is_zero) return 0;
+    DrawStream s;
+    s.init(seed, shot, w);
+    uint64_t word = 0;
+    uint32_t pos = 0;
+    for (;;) {
+        pos += gap_of(q, s.draw());
+        if (pos >= nbits) break;
+        word |= 1ull << pos;
+        pos++;
+        if (pos >= nbits) break;
+    }
+    return word;
+}
+
+// One word of a depolarizing sample (depolarizing.rs:34-48): x part = X or Y,
+// z part = Z or Y (css.rs:92-99).
+__device__ inline void depol_word(const uint32_t *q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
+                                  uint32_t nbits, uint64_t &xw, uint64_t &zw)
+{
+    xw = 0; zw = 0;
+    if (p_is_zero) return;
+    DrawStream s;
+    s.init(seed, shot, w);
+    uint32_t pos = 0;
+    for (;;) {
+        pos += gap_of(q, s.draw());
+        if (pos >= nbits) break;
+        uint32_t pauli = (uint32_t)(((uint64_t)s.draw() * 3u) >> 32);   // 0 = X, 1 = Y, 2 = Z
+        if (pauli <= 1) xw |= 1ull << pos;
+        if (pauli >= 1) zw |= 1ull << pos;
+        pos++;
+        if (pos >= nbits) break;
+    }
+}
+
+__device__ inline uint32_t bits_in_word(uint32_t n, uint32_t w)
+{
+    uint32_t rem = n - w * 64u;
+    return rem < 64u ? rem : 64u;
+}
+#endif  // __HIPCC__
+
+}  // namespace ldpc

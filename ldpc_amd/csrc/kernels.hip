@@ -1,0 +1,589 @@
+// gfx950 kernels of the Monte-Carlo decoding path.
+//
+//   sample_*_kernel   noise (binary_symmetric_channel.rs:35-43, depolarizing.rs:34-48)
+//   syndrome_kernel   H*e over GF(2) (linear_code/mod.rs:393-405)
+//   flip_kernel       FlipDecoder::decode (flip.rs:21-43), fused with noise + syndrome + failure test
+//   bp_kernel         BpDecoder::correction_for (belief_propagation.rs:23-30, 100-180), fused likewise
+//
+// Wavefront = 64 lanes everywhere; bit-packed vectors are built with 64-lane
+// ballots, one u64 word per ballot.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace ldpc {
+
+namespace {
+
+constexpr int CNT_SHOTS = 0, CNT_FAIL = 1, CNT_DET = 2, CNT_UNDET = 3, CNT_WORK = 4, CNT_CAPPED = 5, CNT_XFAIL = 6,
+              CNT_ZFAIL = 7;
+
+// Lanes of one wave exchange data through LDS / global memory: order the
+// accesses (the hardware executes one wave's LDS and vector-memory queues in
+// order; this keeps the compiler from moving accesses across the hand-off and
+// waits for outstanding stores).
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ inline uint64_t wave_or64(uint64_t x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)x, off, 64);
+        uint32_t hi = __shfl_xor((uint32_t)(x >> 32), off, 64);
+        x |= ((uint64_t)hi << 32) | lo;
+    }
+    return x;
+}
+
+__device__ inline uint64_t wave_sum64(uint64_t x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)x, off, 64);
+        uint32_t hi = __shfl_xor((uint32_t)(x >> 32), off, 64);
+        x += ((uint64_t)hi << 32) | lo;
+    }
+    return x;
+}
+
+__device__ inline uint64_t readlane64(uint64_t x, uint32_t l)
+{
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, l);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ inline uint32_t getbit(const uint64_t *w, uint32_t i) { return (uint32_t)(w[i >> 6] >> (i & 63)) & 1u; }
+
+// ---------------------------------------------------------------------------
+// Noise and syndrome, batched (shot-major packed words in HBM)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_bsc_kernel(GapTable gap, uint32_t n, uint64_t seed, uint64_t first,
+                                                         uint64_t n_shots, uint64_t *words)
+{
+    __shared__ uint32_t q[65];
+    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = gap.q[i];
+    __syncthreads();
+    const uint32_t Wn = (n + 63) / 64;
+    const uint64_t total = n_shots * Wn;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = t / Wn;
+        uint32_t w = (uint32_t)(t - i * Wn);
+        words[t] = bsc_word(q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w));
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_depol_kernel(GapTable gap, uint32_t n, uint64_t seed, uint64_t first,
+                                                           uint64_t n_shots, uint64_t *xw, uint64_t *zw)
+{
+    __shared__ uint32_t q[65];
+    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = gap.q[i];
+    __syncthreads();
+    const uint32_t Wn = (n + 63) / 64;
+    const uint64_t total = n_shots * Wn;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = t / Wn;
+        uint32_t w = (uint32_t)(t - i * Wn);
+        uint64_t x, z;
+        depol_word(q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w), x, z);
+        xw[t] = x;
+        zw[t] = z;
+    }
+}
+
+// one wave per shot, one lane per check row, 64 parities -> one ballot word
+__global__ __launch_bounds__(256) void syndrome_kernel(DeviceGraph g, uint64_t n_shots, const uint64_t *words,
+                                                       uint64_t *synd)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n_shots; i += waves) {
+        const uint64_t *e = words + i * Wn;
+        for (uint32_t base = 0; base < g.m; base += 64) {
+            uint32_t c = base + lane, par = 0;
+            if (c < g.m)
+                for (uint32_t k = g.h_ptr[c]; k < g.h_ptr[c + 1]; k++) par ^= getbit(e, g.h_idx[k]);
+            uint64_t mask = __ballot(par);
+            if (lane == 0) synd[i * Wm + (base >> 6)] = mask;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *flags, uint64_t n, unsigned long long *counters)
+{
+    uint64_t f = 0, x = 0, z = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint8_t v = flags[t];
+        f += v != 0;
+        x += v & 1;
+        z += (v >> 1) & 1;
+    }
+    f = wave_sum64(f); x = wave_sum64(x); z = wave_sum64(z);
+    if ((threadIdx.x & 63) == 0) {
+        if (f) atomicAdd(&counters[CNT_FAIL], (unsigned long long)f);
+        if (x) atomicAdd(&counters[CNT_XFAIL], (unsigned long long)x);
+        if (z) atomicAdd(&counters[CNT_ZFAIL], (unsigned long long)z);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Flip decoder.  One wave per shot; the shot's state lives in LDS:
+//   S[Wm]  syndrome, F[Wn] "flippable" mask (unsat > deg/2), O[Wn] output word.
+// The reference rescans from bit 0 after every flip (flip.rs:27,35-43); the
+// choice depends only on the current syndrome, so keeping F up to date for the
+// bits whose checks changed and taking its lowest set bit is the same decision.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    uint32_t *q = (uint32_t *)lds;   // 65 u32 in the first 33 u64
+    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = a.gap.q[i];
+    __syncthreads();
+    uint64_t *S = lds + 33 + (size_t)wave * (Wm + 2 * Wn);
+    uint64_t *F = S + Wm;
+    uint64_t *O = F + Wn;
+    uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
+
+    const uint64_t gw = (uint64_t)blockIdx.x * wpb + wave, waves = (uint64_t)gridDim.x * wpb;
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+
+    for (uint64_t i = gw; i < a.n_shots; i += waves) {
+        const uint64_t shot = a.first_shot + i;
+        // 1. error word (noise on device, or the caller's words)
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            uint32_t nb = bits_in_word(g.n, w);
+            uint64_t x;
+            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+            else {
+                x = a.words_in[i * Wn + w];
+                if (nb < 64) x &= (1ull << nb) - 1;
+            }
+            O[w] = x;
+            if (a.errors_out) a.errors_out[i * Wn + w] = x;
+        }
+        wave_sync();
+        // 2. syndrome: one lane per check, ballot packs 64 checks
+        for (uint32_t base = 0; base < g.m; base += 64) {
+            uint32_t c = base + lane, par = 0;
+            if (c < g.m)
+                for (uint32_t k = g.h_ptr[c]; k < g.h_ptr[c + 1]; k++) par ^= getbit(O, g.h_idx[k]);
+            uint64_t mask = __ballot(par);
+            if (lane == 0) {
+                S[base >> 6] = mask;
+                if (a.synd_out) a.synd_out[i * Wm + (base >> 6)] = mask;
+            }
+        }
+        wave_sync();
+        // 3. flippable mask: one lane per bit
+        for (uint32_t base = 0; base < g.n; base += 64) {
+            uint32_t b = base + lane, flag = 0;
+            if (b < g.n) {
+                uint32_t k0 = g.t_ptr[b], k1 = g.t_ptr[b + 1], unsat = 0;
+                for (uint32_t k = k0; k < k1; k++) unsat += getbit(S, g.t_idx[k]);
+                flag = unsat > (k1 - k0) / 2;   // flip.rs:41
+            }
+            uint64_t mask = __ballot(flag);
+            if (lane == 0) F[base >> 6] = mask;
+        }
+        wave_sync();
+        // 4. serial flips, lowest index first
+        uint32_t nflips = 0;
+        for (;;) {
+            int64_t bsel = -1;
+            for (uint32_t wbase = 0; wbase < Wn; wbase += 64) {
+                uint32_t w = wbase + lane;
+                uint64_t x = w < Wn ? F[w] : 0;
+                uint64_t nz = __ballot(x != 0);
+                if (nz) {
+                    uint32_t l = (uint32_t)__builtin_ctzll(nz);
+                    uint64_t xw = readlane64(x, l);
+                    bsel = (int64_t)(wbase + l) * 64 + __builtin_ctzll(xw);
+                    break;
+                }
+            }
+            if (bsel < 0) break;                                           // flip.rs:27 None
+            const uint32_t b = (uint32_t)bsel;
+            nflips++;
+            const uint32_t k0 = g.t_ptr[b], deg = g.t_ptr[b + 1] - k0;
+            if (lane == 0) O[b >> 6] ^= 1ull << (b & 63);                  // flip.rs:30
+            for (uint32_t kk = lane; kk < deg; kk += 64) {                 // flip.rs:29 syndrome ^= H e_b
+                uint32_t c = g.t_idx[k0 + kk];
+                atomicXor(&S32[c >> 5], 1u << (c & 31));
+            }
+            wave_sync();
+            // refresh F for every bit that shares a check with b
+            for (uint32_t i2 = 0; i2 < deg; i2++) {
+                uint32_t c = g.t_idx[k0 + i2];
+                uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+                for (uint32_t j = lane; j < dc; j += 64) {
+                    uint32_t bb = g.h_idx[e0 + j];
+                    uint32_t kk0 = g.t_ptr[bb], kk1 = g.t_ptr[bb + 1], unsat = 0;
+                    for (uint32_t k = kk0; k < kk1; k++) unsat += getbit(S, g.t_idx[k]);
+                    uint32_t bitm = 1u << (bb & 31);
+                    if (unsat > (kk1 - kk0) / 2) atomicOr(&F32[bb >> 5], bitm);
+                    else atomicAnd(&F32[bb >> 5], ~bitm);
+                }
+            }
+            wave_sync();
+        }
+        // 5. failure test (all-zero codeword) and outputs
+        uint64_t anyo = 0, anys = 0;
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            uint64_t x = O[w];
+            anyo |= x;
+            if (a.words_out) a.words_out[i * Wn + w] = x;
+        }
+        for (uint32_t w = lane; w < Wm; w += 64) anys |= S[w];
+        bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
+        if (a.flips_out && lane == 0) a.flips_out[i] = nflips;
+        c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nflips;
+        wave_sync();
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+        if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
+        if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Belief propagation.  One wave owns a group of 64 shot slots, lane = slot.
+// Messages are laid out [edge][slot] (f64) in check-major edge order, so every
+// message access of the wave is one coalesced 512-byte row and every graph
+// index is wave-uniform.  A slot whose shot stops (syndrome matched or
+// iteration cap) is harvested and refilled with the group's next shot.
+// ---------------------------------------------------------------------------
+constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
+
+// f64::atanh of the reference's toolchain: 0.5 * ln_1p(2x / (1 - x))
+__device__ inline double ref_atanh(double x) { return 0.5 * log1p((2.0 * x) / (1.0 - x)); }
+
+__global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
+{
+    __shared__ uint32_t q[65];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
+    __syncthreads();
+    const uint32_t n = g.n, m = g.m;
+    const uint32_t Wn = (n + 63) / 64, Wm = (m + 63) / 64;
+    const size_t grp = blockIdx.x;
+    double *bitsm = a.msg + grp * 2 * (size_t)g.E * 64;
+    double *chkm = bitsm + (size_t)g.E * 64;
+    uint64_t *ew = a.ew + grp * (size_t)Wn * 64;
+    uint64_t *dw = a.dw + grp * (size_t)Wn * 64;
+    uint64_t *dsl = a.dsl + grp * (size_t)n;
+    uint64_t *ssl = a.ssl + grp * (size_t)m;
+    const double prior = a.prior;
+
+    uint64_t next = grp * a.quota;
+    uint64_t end = next + a.quota < a.n_shots ? next + a.quota : a.n_shots;
+    if (next > end) next = end;
+
+    bool active = false, fresh = false;
+    uint32_t iter = 0;
+    uint64_t myi = 0;
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;
+
+    for (;;) {
+        // ---- refill idle slots with the group's next shots -------------------
+        {
+            uint64_t idle = __ballot(!active);
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+            bool take = !active && (uint64_t)rank < end - next;
+            uint64_t takemask = __ballot(take);
+            if (takemask) {
+                if (take) { myi = next + rank; active = true; fresh = true; iter = 0; }
+                next += (uint64_t)__builtin_popcountll(takemask);
+                const uint64_t shot = a.first_shot + myi;
+                if (a.source != SRC_SYNDROMES) {
+                    for (uint32_t w = 0; w < Wn; w++) {
+                        if (take) {
+                            uint32_t nb = bits_in_word(n, w);
+                            uint64_t x;
+                            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+                            else if (a.source == SRC_WORDS) {
+                                x = a.words_in[myi * Wn + w];
+                                if (nb < 64) x &= (1ull << nb) - 1;
+                            } else {
+                                uint64_t xx, zz;
+                                depol_word(q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
+                                x = a.source == SRC_DEPOL_X ? xx : zz;
+                            }
+                            ew[(size_t)w * 64 + lane] = x;
+                        }
+                    }
+                    for (uint32_t c = 0; c < m; c++) {
+                        uint32_t par = 0;
+                        const uint32_t e0 = g.h_ptr[c], e1 = g.h_ptr[c + 1];
+                        for (uint32_t e = e0; e < e1; e++) {
+                            uint32_t b = g.h_idx[e];
+                            if (take) par ^= (uint32_t)(ew[(size_t)(b >> 6) * 64 + lane] >> (b & 63)) & 1u;
+                        }
+                        uint64_t mask = __ballot(take && par);
+                        if (lane == 0) ssl[c] = (ssl[c] & ~takemask) | mask;
+                    }
+                } else {
+                    for (uint32_t c = 0; c < m; c++) {
+                        uint32_t sb = 0;
+                        if (take) sb = (uint32_t)(a.synd_in[myi * Wm + (c >> 6)] >> (c & 63)) & 1u;
+                        uint64_t mask = __ballot(take && sb);
+                        if (lane == 0) ssl[c] = (ssl[c] & ~takemask) | mask;
+                    }
+                }
+                // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
+                const bool init = prior < 0.0;
+                for (uint32_t b = lane; b < n; b += 64) dsl[b] = (dsl[b] & ~takemask) | (init ? takemask : 0ull);
+                if (take)
+                    for (uint32_t w = 0; w < Wn; w++) {
+                        uint32_t nb = bits_in_word(n, w);
+                        dw[(size_t)w * 64 + lane] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
+                    }
+                wave_sync();
+            }
+        }
+        const uint64_t actmask = __ballot(active);
+        if (!actmask) break;
+
+        // ---- stop test (belief_propagation.rs:26-27), bit-sliced over the 64 slots:
+        // lanes split the checks, each XORs whole 64-slot words
+        uint64_t mism = 0;
+        for (uint32_t c = lane; c < m; c += 64) {
+            uint64_t x = ssl[c];
+            for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= dsl[g.h_idx[e]];
+            mism |= x;
+        }
+        mism = wave_or64(mism);
+        const bool conv = !((mism >> lane) & 1ull);
+        const bool done = active && (conv || iter >= a.max_iter);
+        const uint64_t donemask = __ballot(done);
+
+        if (donemask) {
+            // ---- harvest ------------------------------------------------------
+            bool fail = false, det = !conv;
+            if (a.test != TEST_NONE) {
+                uint64_t rany = 0;
+                for (uint32_t w = 0; w < Wn; w++)
+                    if (done) rany |= ew[(size_t)w * 64 + lane] ^ dw[(size_t)w * 64 + lane];
+                if (a.test == TEST_RESIDUAL) fail = rany != 0;
+                else {
+                    uint32_t lfail = 0;
+                    for (uint32_t r = 0; r < a.l_rows; r++) {
+                        uint32_t par = 0;
+                        for (uint32_t k = a.l_ptr[r]; k < a.l_ptr[r + 1]; k++) {
+                            uint32_t b = a.l_idx[k];
+                            if (done) {
+                                size_t off = (size_t)(b >> 6) * 64 + lane;
+                                par ^= (uint32_t)((ew[off] ^ dw[off]) >> (b & 63)) & 1u;
+                            }
+                        }
+                        lfail |= par;
+                    }
+                    fail = det || lfail;
+                }
+            }
+            if (done) {
+                if (a.iters_out) a.iters_out[myi] = iter;
+                if (a.corr_out)
+                    for (uint32_t w = 0; w < Wn; w++) {
+                        uint64_t x = dw[(size_t)w * 64 + lane];
+                        if (a.xor_input) x ^= ew[(size_t)w * 64 + lane];
+                        a.corr_out[myi * Wn + w] = x;
+                    }
+                if (a.post_out)
+                    for (uint32_t b = 0; b < n; b++) {      // BpState::decode posterior, :100-106
+                        double l = prior;
+                        if (!fresh)
+                            for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) l += chkm[(size_t)g.t_edge[k] * 64 + lane];
+                        a.post_out[myi * n + b] = l;
+                    }
+                if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
+                c_shots++; c_fail += fail; c_det += det; c_work += iter;
+                active = false;
+            }
+            if (next < end) continue;   // refill before spending an iteration
+            if (!__ballot(active)) break;
+        }
+
+        // ---- one BP iteration on the active slots (update_once, :133-140) -----
+        // update_checks (:150-166)
+        for (uint32_t c = 0; c < m; c++) {
+            const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+            const bool sbit = (ssl[c] >> lane) & 1ull;
+            if (dc <= REG_DEG) {
+                double t[REG_DEG];
+                double prod = 1.0;
+#pragma unroll
+                for (uint32_t j = 0; j < REG_DEG; j++)
+                    if (j < dc) {
+                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                        t[j] = tanh(x / 2.0);
+                        prod *= t[j];
+                    }
+#pragma unroll
+                for (uint32_t j = 0; j < REG_DEG; j++)
+                    if (j < dc) {
+                        double v = 2.0 * ref_atanh(prod / t[j]);
+                        if (sbit) v *= -1.0;
+                        if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
+                    }
+            } else {
+                double prod = 1.0;
+                for (uint32_t j = 0; j < dc; j++) {
+                    double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                    prod *= tanh(x / 2.0);
+                }
+                for (uint32_t j = 0; j < dc; j++) {
+                    double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                    double v = 2.0 * ref_atanh(prod / tanh(x / 2.0));
+                    if (sbit) v *= -1.0;
+                    if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
+                }
+            }
+        }
+        // update_bits (:168-180) + hard decision (:100-113)
+        uint64_t dacc = 0, slice = 0;
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
+            double sum = 0.0, post = prior;
+            if (dv <= REG_DEG) {
+                double v[REG_DEG];
+                uint32_t ed[REG_DEG];
+#pragma unroll
+                for (uint32_t k = 0; k < REG_DEG; k++)
+                    if (k < dv) {
+                        ed[k] = g.t_edge[k0 + k];
+                        v[k] = chkm[(size_t)ed[k] * 64 + lane];
+                        sum += v[k];
+                        post += v[k];
+                    }
+#pragma unroll
+                for (uint32_t k = 0; k < REG_DEG; k++)
+                    if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+            } else {
+                for (uint32_t k = 0; k < dv; k++) {
+                    double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
+                    sum += v;
+                    post += v;
+                }
+                for (uint32_t k = 0; k < dv; k++) {
+                    size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
+                    if (active) bitsm[off] = sum - chkm[off] + prior;
+                }
+            }
+            const bool dec = post < 0.0;
+            dacc |= (uint64_t)dec << (b & 63);
+            uint64_t mask = __ballot(active && dec);
+            if (lane == (b & 63)) slice = mask;
+            if ((b & 63) == 63 || b == n - 1) {
+                if (active) dw[(size_t)(b >> 6) * 64 + lane] = dacc;
+                uint32_t bb = (b & ~63u) + lane;
+                if (bb <= b) dsl[bb] = (dsl[bb] & ~actmask) | slice;
+                dacc = 0;
+                slice = 0;
+            }
+        }
+        if (active) { iter++; fresh = false; }
+        wave_sync();
+    }
+    c_shots = wave_sum64(c_shots); c_fail = wave_sum64(c_fail); c_det = wave_sum64(c_det); c_work = wave_sum64(c_work);
+    if (lane == 0 && a.counters) {
+        if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) {
+            atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+            atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_det);
+        }
+        if (c_fail - c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
+        if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap)
+{
+    uint64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (uint32_t)(b < cap ? b : cap);
+}
+
+size_t bp_workspace_bytes_per_group(const DeviceGraph &g)
+{
+    size_t Wn = (g.n + 63) / 64;
+    return 2 * (size_t)g.E * 64 * sizeof(double) + 2 * Wn * 64 * sizeof(uint64_t) + ((size_t)g.n + g.m) * sizeof(uint64_t);
+}
+
+hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
+                             uint64_t *d_words, hipStream_t st)
+{
+    uint64_t total = n_shots * ((n + 63) / 64);
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(sample_bsc_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, gap, n, seed, first,
+                       n_shots, d_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_depol(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
+                               uint64_t *d_x, uint64_t *d_z, hipStream_t st)
+{
+    uint64_t total = n_shots * ((n + 63) / 64);
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(sample_depol_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, gap, n, seed, first,
+                       n_shots, d_x, d_z);
+    return hipGetLastError();
+}
+
+hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_t *d_words, uint64_t *d_synd,
+                           hipStream_t st)
+{
+    if (!n_shots || !g.m) return hipSuccess;
+    hipLaunchKernelGGL(syndrome_kernel, dim3(grid_for(n_shots, 4, 8192)), dim3(256), 0, st, g, n_shots, d_words, d_synd);
+    return hipGetLastError();
+}
+
+hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    size_t per_wave = (Wm + 2 * Wn) * 8;
+    uint32_t wpb = 4;
+    while (wpb > 1 && 33 * 8 + wpb * per_wave > 64 * 1024) wpb >>= 1;
+    size_t lds = 33 * 8 + wpb * per_wave;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;   // caller reports LDPC_ERR_CAPACITY
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)flip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(flip_kernel, dim3(grid_for(a.n_shots, wpb, 256 * 8)), dim3(wpb * 64), lds, st, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, hipStream_t st)
+{
+    if (!a.n_shots || !groups) return hipSuccess;
+    hipLaunchKernelGGL(bp_kernel, dim3(groups), dim3(64), 0, st, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(count_flags_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, d_flags, n, d_counters);
+    return hipGetLastError();
+}
+
+}  // namespace ldpc

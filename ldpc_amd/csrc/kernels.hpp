@@ -1,0 +1,78 @@
+// Kernel argument blocks and host-side launchers (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_common.hpp"
+
+namespace ldpc {
+
+enum NoiseSource : int {
+    SRC_BSC = 0,          // sample BSC(p) on device
+    SRC_DEPOL_X = 1,      // sample depolarizing(p), keep the x part (X or Y)
+    SRC_DEPOL_Z = 2,      // sample depolarizing(p), keep the z part (Z or Y)
+    SRC_WORDS = 3,        // read error / message words
+    SRC_SYNDROMES = 4     // read syndromes (correction_for)
+};
+
+enum FailureTest : int {
+    TEST_NONE = 0,
+    TEST_RESIDUAL = 1,    // classical, all-zero codeword: residual != 0
+    TEST_LOGICAL = 2      // CSS half: H*residual != 0 or L*residual != 0
+};
+
+struct FlipArgs {
+    int source;                 // SRC_BSC or SRC_WORDS
+    uint64_t seed, first_shot, n_shots;
+    const uint64_t *words_in;   // [n_shots][Wn]       (SRC_WORDS)
+    uint64_t *errors_out;       // [n_shots][Wn]  or null
+    uint64_t *synd_out;         // [n_shots][Wm]  or null: H * input
+    uint64_t *words_out;        // [n_shots][Wn]  or null: decoded word
+    uint32_t *flips_out;        // [n_shots]      or null
+    unsigned long long *counters;   // [LDPC_COUNTERS] device, accumulated
+    GapTable gap;
+};
+
+struct BpArgs {
+    int source;
+    int test;
+    int xor_input;              // decode(): output = input ^ correction
+    uint32_t max_iter;
+    uint32_t fail_bit;          // OR-ed into failed_out on failure
+    double prior;               // ln((1-p)/p), belief_propagation.rs:38
+    uint64_t seed, first_shot, n_shots, quota;
+    const uint64_t *words_in;   // [n_shots][Wn]
+    const uint64_t *synd_in;    // [n_shots][Wm]
+    uint64_t *corr_out;         // [n_shots][Wn] or null
+    uint32_t *iters_out;        // [n_shots]     or null
+    double *post_out;           // [n_shots][n]  or null
+    uint8_t *failed_out;        // [n_shots]     or null
+    unsigned long long *counters;
+    // logical test matrix (rows = logical generators), TEST_LOGICAL only
+    uint32_t l_rows;
+    const uint32_t *l_ptr, *l_idx;
+    // workspace, one slice per shot group (64 shots)
+    double *msg;                // [groups][2][E][64]
+    uint64_t *ew;               // [groups][Wn][64] error words of the slot's shot
+    uint64_t *dw;               // [groups][Wn][64] hard decisions, packed per slot
+    uint64_t *dsl;              // [groups][n]      hard decisions, bit-sliced over slots
+    uint64_t *ssl;              // [groups][m]      syndromes, bit-sliced over slots
+    GapTable gap;
+};
+
+size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
+
+hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
+                             uint64_t *d_words, hipStream_t st);
+hipError_t launch_sample_depol(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
+                               uint64_t *d_x, uint64_t *d_z, hipStream_t st);
+hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_t *d_words, uint64_t *d_synd,
+                           hipStream_t st);
+hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st);
+hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, hipStream_t st);
+// counters[FAILURES] += #{flags != 0}, [XFAIL] += #{flags & 1}, [ZFAIL] += #{flags & 2}
+hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
+
+}  // namespace ldpc

@@ -1,0 +1,109 @@
+"""Flip decoder on the MI355X against the CPU oracle: bit-exact words, syndromes, flip counts."""
+import numpy as np
+import pytest
+
+from ldpc_amd import (CNT_DETECTED, CNT_FAILURES, CNT_SHOTS, CNT_UNDETECTED, CNT_WORK, BinarySymmetricChannel,
+                      FlipDecoder, LinearCode, nwords)
+from oracle import oracle as orc
+from tests.gpu_util import dev_u32, dev_u64, host_u32, host_u64, oracle_code, random_sparse_rows, to_dev_u64
+
+pytestmark = pytest.mark.gpu
+
+SEED = 2024
+
+
+def test_flip_golden_c1():
+    g = np.load("tests/golden/c1_vectors.npz")
+    code = LinearCode.from_csr(1200, g["h_ptr"], g["h_idx"])
+    dec = FlipDecoder(code)
+    shots = g["errors"].shape[0]
+    de, ds, do = dev_u64(g["errors"].shape), dev_u64(g["syndromes"].shape), dev_u64(g["flip_out"].shape)
+    cnt = dec.mc_run(0.02, SEED, 0, shots, de, ds, do)
+    assert (host_u64(de) == g["errors"]).all()
+    assert (host_u64(ds) == g["syndromes"]).all()
+    assert (host_u64(do) == g["flip_out"]).all()
+    assert cnt[CNT_WORK] == g["flip_count"].sum() and cnt[CNT_SHOTS] == shots
+    # the same shots through the batch entry point
+    df, do2, ds2 = dev_u32((shots,)), dev_u64(g["flip_out"].shape), dev_u64(g["syndromes"].shape)
+    dec.decode_batch(shots, to_dev_u64(g["errors"]), do2, ds2, df)
+    assert (host_u64(do2) == g["flip_out"]).all() and (host_u64(ds2) == g["syndromes"]).all()
+    assert (host_u32(df) == g["flip_count"]).all()
+
+
+def test_flip_mc_counters_c1_full():
+    # BASELINE configs[0]: (3,4) n=1200, p=0.02, 1e4 shots
+    g = np.load("tests/golden/c1_vectors.npz")
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+    assert (code.csr()[1] == g["h_idx"]).all()
+    cnt = FlipDecoder(code).mc_run(0.02, SEED, 0, 10000)
+    assert (cnt == g["c1_flip_counters_10000"]).all()
+
+
+@pytest.mark.parametrize("n,m,dv,dc,p,shots", [(1200, 900, 3, 4, 0.02, 512), (10000, 5000, 3, 6, 0.02, 256),
+                                               (10000, 5000, 3, 6, 0.05, 64), (4, 3, 3, 4, 0.2, 64)])
+def test_flip_matches_oracle(n, m, dv, dc, p, shots):
+    code = LinearCode.random_regular_code(n, m, dv, dc, seed=1)
+    oc = oracle_code(code)
+    dec = FlipDecoder(code)
+    de, ds, do = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u64((shots, nwords(n)))
+    first = 777
+    cnt = dec.mc_run(p, SEED, first, shots, de, ds, do)
+    ge, gs, go = host_u64(de), host_u64(ds), host_u64(do)
+    fails = det = flips = 0
+    for i in range(shots):
+        e = orc.sample_bsc_words(SEED, first + i, p, n)
+        o, s_final, nf = oc.flip_decode_words(e)
+        assert (ge[i] == e).all()
+        assert (gs[i] == oc.syndrome_words(e)).all()
+        assert (go[i] == o).all()
+        fails += bool(o.any()); det += bool(s_final.any()); flips += nf
+    assert cnt[CNT_SHOTS] == shots and cnt[CNT_FAILURES] == fails and cnt[CNT_DETECTED] == det
+    assert cnt[CNT_UNDETECTED] == fails - det and cnt[CNT_WORK] == flips
+
+
+def test_flip_irregular_and_ragged():
+    rng = np.random.default_rng(3)
+    shapes = [(1, 0), (1, 1), (63, 10), (64, 64), (65, 33), (129, 200), (300, 7)]
+    for (n, m) in shapes:
+        rows = random_sparse_rows(rng, n, m, 8)
+        code = LinearCode.from_parity_check_matrix(n, rows)
+        oc = oracle_code(code)
+        dec = FlipDecoder(code)
+        shots = 48
+        words = np.zeros((shots, nwords(n)), dtype=np.uint64)
+        for i in range(shots):
+            words[i] = orc.sample_bsc_words(9, i, 0.2, n)
+        do, ds, df = dev_u64((shots, nwords(n))), dev_u64((shots, max(nwords(m), 1))), dev_u32((shots,))
+        dec.decode_batch(shots, to_dev_u64(words), do, ds, df)
+        go, gf = host_u64(do), host_u32(df)
+        for i in range(shots):
+            o, _, nf = oc.flip_decode_words(words[i])
+            assert (go[i] == o).all() and gf[i] == nf
+            # and the reference-style restatement on position lists
+            ref, nf2 = oc.flip_decode(orc.words_to_pos(words[i], n))
+            assert orc.words_to_pos(go[i], n) == ref and nf2 == nf
+
+
+def test_flip_full_size_properties():
+    # C2 shape, 2^16 shots: decode is idempotent, the recorded syndrome is H*error,
+    # counters add up over a split shot range (noise is keyed by the global shot index)
+    n, m, shots = 10000, 5000, 1 << 16
+    code = LinearCode.random_regular_code(n, m, 3, 6, seed=1)
+    dec = FlipDecoder(code)
+    de, ds, do = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u64((shots, nwords(n)))
+    cnt = dec.mc_run(0.02, SEED, 0, shots, de, ds, do)
+    chk = dev_u64((shots, nwords(m)))
+    code.syndrome_batch(shots, de, chk)
+    assert bool((chk == ds).all())
+    do2, df = dev_u64((shots, nwords(n))), dev_u32((shots,))
+    dec.decode_batch(shots, do, do2, None, df)
+    assert bool((do2 == do).all()) and int(df.sum()) == 0
+    # failures counted == decoded words that are non-zero
+    assert int((do != 0).any(dim=1).sum()) == cnt[CNT_FAILURES]
+    code.syndrome_batch(shots, do, chk)
+    assert int((chk != 0).any(dim=1).sum()) == cnt[CNT_DETECTED]
+    a = dec.mc_run(0.02, SEED, 0, shots // 2)
+    b = dec.mc_run(0.02, SEED, shots // 2, shots - shots // 2)
+    assert ((a + b) == cnt).all()
+    mean_w = float(sum(bin(int(x)).count("1") for x in host_u64(de[:64]).ravel())) / 64
+    assert 150 < mean_w < 250
