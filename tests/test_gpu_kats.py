@@ -68,16 +68,23 @@ def test_hgp_logicals(kats):
     assert not surface.has_stabilizer([], d["logical_z"])
 
 
-def test_css_decoder_swap_convention():
-    # decoders/css.rs:10-15 on the Shor code: a single Z error on qubit 7 fires
-    # x-stabilizer 1; the correction must come back in the z part
+def test_css_decoder_swap_convention(kats):
+    # decoders/css.rs:10-15 on the Shor code: correction.z comes from the x decoder
+    # (BP on Hx, fed syndrome.x), correction.x from the z decoder (BP on Hz)
+    import numpy as np
+    from oracle import oracle as orc
+    d = kats["shor"]
     code = CssCode.shor_code()
     dec = CssDecoder(code, 0.05, 20)
-    sx, sz = code.syndrome_of([], [7])
-    cx, cz = dec.correction_for(sx, sz)
-    assert cx == []
-    assert code.has_stabilizer([], sorted(set(cz) ^ {7}))
+    hx, hz = orc.Code(9, rows=d["hx"]), orc.Code(9, rows=d["hz"])
+    for xp, zp in (([], [7]), ([1], []), ([1], [7]), ([0, 4], [2, 3])):
+        sx, sz = code.syndrome_of(xp, zp)
+        cx, cz = dec.correction_for(sx, sz)
+        ocz, _, _ = hx.bp_correction_for(0.05, 20, orc.pos_to_words(sx, 2))
+        ocx, _, _ = hz.bp_correction_for(0.05, 20, orc.pos_to_words(sz, 6))
+        assert cx == orc.words_to_pos(ocx, 9) and cz == orc.words_to_pos(ocz, 9)
+    # a single X error is unambiguous for the weight-2 Z checks: corrected exactly
     sx, sz = code.syndrome_of([1], [])
     cx, cz = dec.correction_for(sx, sz)
-    assert cz == []
-    assert code.syndrome_of(cx, []) == ([], sz)
+    assert cz == [] and code.syndrome_of(cx, []) == ([], sz)
+    assert code.has_stabilizer(sorted(set(cx) ^ {1}), [])
