@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -182,7 +183,9 @@ struct ldpc_css_code {
 struct ldpc_flip_decoder {
     ldpc_code code;
     std::mutex mu;
-    DeviceBuffer counters;
+    DeviceBuffer counters, nb;
+    NbTable nbt{};
+    int path = 0;   // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel
 };
 
 struct ldpc_bp_decoder {
@@ -243,6 +246,49 @@ int zero_counters(DeviceBuffer &d)
 // ---------------------------------------------------------------------------
 // flip driver
 // ---------------------------------------------------------------------------
+// Neighbourhood table of the fast flip kernel (kernels.hpp NbTable).  Returns
+// false when the code does not suit it (bit degree > 7, table > 1 GiB).
+bool build_nb_table(const LinearCode &c, std::vector<uint32_t> &out, uint32_t &kshift, uint32_t &dvp)
+{
+    const SparseBinMat &h = c.h, &t = c.ht;
+    const uint32_t n = h.ncols;
+    const uint32_t max_dv = t.max_row_len();
+    if (max_dv > 7) return false;
+    dvp = max_dv <= 3 ? 3 : 7;
+    std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
+    uint32_t kmax = 1;
+    for (uint32_t b = 0; b < n; b++) {
+        uint32_t cnt = 1;
+        stamp[b] = b;
+        for (uint32_t k = t.ptr[b]; k < t.ptr[b + 1]; k++)
+            for (uint32_t e = h.ptr[t.idx[k]]; e < h.ptr[t.idx[k] + 1]; e++)
+                if (stamp[h.idx[e]] != b) { stamp[h.idx[e]] = b; cnt++; }
+        kmax = std::max(kmax, cnt);
+    }
+    kshift = 4;
+    while ((1u << kshift) < kmax) kshift++;
+    const size_t K = (size_t)1 << kshift, rec = 1 + dvp;
+    if ((size_t)n * K * rec * 4 > ((size_t)1 << 30)) return false;
+    out.assign((size_t)n * K * rec, 0xFFFFFFFFu);
+    std::fill(stamp.begin(), stamp.end(), 0xFFFFFFFFu);
+    auto put = [&](uint32_t b, size_t slot, uint32_t bit) {
+        uint32_t *r = &out[((size_t)b * K + slot) * rec];
+        r[0] = bit;
+        for (uint32_t k = t.ptr[bit]; k < t.ptr[bit + 1]; k++) r[1 + (k - t.ptr[bit])] = t.idx[k];
+    };
+    for (uint32_t b = 0; b < n; b++) {
+        size_t slot = 0;
+        stamp[b] = b;
+        put(b, slot++, b);
+        for (uint32_t k = t.ptr[b]; k < t.ptr[b + 1]; k++)
+            for (uint32_t e = h.ptr[t.idx[k]]; e < h.ptr[t.idx[k] + 1]; e++) {
+                uint32_t bb = h.idx[e];
+                if (stamp[bb] != b) { stamp[bb] = b; put(b, slot++, bb); }
+            }
+    }
+    return true;
+}
+
 int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
 {
     int st = dec->code.ensure_device();
@@ -252,6 +298,30 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
     if (st) return st;
     a.counters = dec->counters.as<unsigned long long>();
     const DeviceGraph &g = dec->code.dg;
+    if (dec->path == 0) {
+        dec->path = 1;
+        std::vector<uint32_t> tab;
+        uint32_t kshift = 0, dvp = 0;
+        const char *force = std::getenv("LDPC_HIP_FLIP_KERNEL");   // "csr" forces the generic kernel (tests)
+        const bool allow_fast = !(force && std::strcmp(force, "csr") == 0);
+        if (allow_fast && flip2_lds_bytes(g) <= 64 * 1024 && g.n < (1u << 26) &&
+            build_nb_table(dec->code.host, tab, kshift, dvp)) {
+            HIP_TRY(dec->nb.reserve(std::max<size_t>(tab.size(), 1) * 4));
+            if (!tab.empty()) HIP_TRY(hipMemcpy(dec->nb.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            dec->nbt.rec = dec->nb.as<uint32_t>();
+            dec->nbt.kshift = kshift;
+            dec->nbt.dvp = dvp;
+            dec->path = 2;
+        }
+    }
+    if (dec->path == 2) {
+        KernelTimer timer;
+        HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
+        timer.stop_and_store();
+        if (counters_out) return read_counters(dec->counters, counters_out);
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return LDPC_OK;
+    }
     size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
     if (33 * 8 + per_wave > 160 * 1024)
         return fail(LDPC_ERR_CAPACITY, "flip decoder: per-shot state of " + std::to_string(per_wave) +

@@ -9,6 +9,8 @@
 // ballots, one u64 word per ballot.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace ldpc {
@@ -247,6 +249,215 @@ __global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
         if (a.flips_out && lane == 0) a.flips_out[i] = nflips;
         c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nflips;
         wave_sync();
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+        if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
+        if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Flip decoder, fast path.  One wave carries FOUR shots: the serial flip loop
+// of a shot only ever touches the <= K bits around the flipped bit, so a group
+// of 16 lanes per shot runs it (K slots = one or more rounds of 16), and the
+// four groups of a wave advance four independent serial chains in lockstep.
+// The set-up of a shot (noise, syndrome, initial flippable mask) is done
+// wave-wide and sparsely: the sampled error positions are compacted into an LDS
+// list, pass 1 toggles the checks of every error bit, pass 2 evaluates only the
+// bits in the neighbourhood of an error bit (all other bits see no unsatisfied
+// check and cannot be flippable).
+// ---------------------------------------------------------------------------
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t LIST_CAP = 1024;          // u16 entries; a 16-word sub-round never exceeds it
+constexpr uint32_t FLIP2_HDR = 33 + LIST_CAP / 4 + 1;   // u64 words: gap table, list, list counter
+
+template <int DVP> struct alignas(16) NbRec {
+    uint32_t bit;
+    uint32_t chk[DVP];
+};
+
+template <int DVP> __device__ inline bool rec_flippable(const NbRec<DVP> &r, const uint32_t *S32)
+{
+    uint32_t deg = 0, unsat = 0;
+#pragma unroll
+    for (int k = 0; k < DVP; k++) {
+        const uint32_t c = r.chk[k];
+        const bool valid = c != NONE;
+        const uint32_t word = S32[valid ? (c >> 5) : 0];
+        deg += valid;
+        unsat += valid ? ((word >> (c & 31)) & 1u) : 0u;
+    }
+    return unsat > deg / 2;   // flip.rs:41
+}
+
+__device__ inline uint32_t wave_sum32(uint32_t x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+template <int DVP> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    const uint32_t per_shot = Wm + 2 * Wn;
+    uint32_t *q = (uint32_t *)lds;
+    uint16_t *list = (uint16_t *)(lds + 33);
+    uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 4);
+    uint64_t *state = lds + FLIP2_HDR;
+    const NbRec<DVP> *nb = (const NbRec<DVP> *)nbt.rec;
+    const uint32_t kshift = nbt.kshift, K = 1u << kshift;
+
+    for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
+    wave_sync();
+
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+
+    for (uint64_t base = (uint64_t)blockIdx.x * 4; base < a.n_shots; base += (uint64_t)gridDim.x * 4) {
+        const uint32_t nvalid = a.n_shots - base < 4 ? (uint32_t)(a.n_shots - base) : 4u;
+        // ------------------------------------------------------------------ set-up
+        for (uint32_t j = 0; j < nvalid; j++) {
+            uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = F + Wn;
+            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
+            const uint64_t i = base + j, shot = a.first_shot + i;
+            for (uint32_t w = lane; w < Wm; w += 64) S[w] = 0;
+            for (uint32_t w = lane; w < Wn; w += 64) {
+                const uint32_t nb_bits = bits_in_word(g.n, w);
+                uint64_t x;
+                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
+                else {
+                    x = a.words_in[i * Wn + w];
+                    if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
+                }
+                F[w] = 0;
+                O[w] = x;
+                if (a.errors_out) a.errors_out[i * Wn + w] = x;
+            }
+            wave_sync();
+            for (int pass = 0; pass < 2; pass++) {
+                for (uint32_t wb = 0; wb < Wn; wb += 64) {
+                    const uint32_t w = wb + lane;
+                    const uint64_t x = w < Wn ? O[w] : 0;
+                    const uint32_t total = wave_sum32((uint32_t)__builtin_popcountll(x));
+                    if (total == 0) continue;
+                    const uint32_t nsub = total <= LIST_CAP ? 1u : 4u;
+                    for (uint32_t sub = 0; sub < nsub; sub++) {
+                        if (lane == 0) *cnt_lds = 0;
+                        wave_sync();
+                        uint64_t xx = (nsub == 1 || grp == sub) ? x : 0;
+                        const uint32_t cc = (uint32_t)__builtin_popcountll(xx);
+                        uint32_t off = cc ? atomicAdd(cnt_lds, cc) : 0;
+                        while (xx) {
+                            list[off++] = (uint16_t)(lane * 64 + (uint32_t)__builtin_ctzll(xx));
+                            xx &= xx - 1;
+                        }
+                        wave_sync();
+                        const uint32_t cnt = __builtin_amdgcn_readfirstlane(*cnt_lds);
+                        if (pass == 0) {
+                            // syndrome: toggle the checks of every error bit (slot 0 of its row)
+                            for (uint32_t t = lane; t < cnt; t += 64) {
+                                const uint32_t e = wb * 64 + list[t];
+                                const NbRec<DVP> r = nb[(size_t)e << kshift];
+#pragma unroll
+                                for (int k = 0; k < DVP; k++)
+                                    if (r.chk[k] != NONE) atomicXor(&S32[r.chk[k] >> 5], 1u << (r.chk[k] & 31));
+                            }
+                        } else {
+                            // flippable mask: only bits next to an error bit can see an unsatisfied check
+                            for (uint32_t t = lane; t < (cnt << kshift); t += 64) {
+                                const uint32_t e = wb * 64 + list[t >> kshift];
+                                const NbRec<DVP> r = nb[((size_t)e << kshift) + (t & (K - 1))];
+                                if (r.bit != NONE && rec_flippable<DVP>(r, S32)) atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                            }
+                        }
+                        wave_sync();
+                    }
+                }
+                if (pass == 0 && a.synd_out)
+                    for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+            }
+        }
+        // ------------------------------------------------------------------ serial flips, 4 shots in lockstep
+        {
+            uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm, *O = F + Wn;
+            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *O32 = (uint32_t *)O;
+            bool active = grp < nvalid;
+            uint32_t cur = 0, nfl = 0;   // invariant: no flippable bit below word `cur`
+            while (__ballot(active)) {
+                const uint32_t w = cur + gl;
+                const uint64_t x = (active && w < Wn) ? F[w] : 0;
+                const uint64_t nz = __ballot(x != 0);
+                const uint32_t gm = (uint32_t)(nz >> (grp * 16)) & 0xFFFFu;
+                const bool found = active && gm != 0;
+                if (active && !found) {
+                    cur += 16;
+                    if (cur >= Wn) active = false;                      // flip.rs:27 find_flippable == None
+                }
+                const uint32_t l = found ? (uint32_t)__builtin_ctz(gm) : 0u;
+                const uint32_t src = (grp << 4) + l;
+                const uint32_t xlo = __shfl((uint32_t)x, src, 64), xhi = __shfl((uint32_t)(x >> 32), src, 64);
+                const uint64_t xw = ((uint64_t)xhi << 32) | xlo;
+                const uint32_t b = found ? (cur + l) * 64 + (uint32_t)__builtin_ctzll(xw) : 0u;
+                NbRec<DVP> rec;
+                rec.bit = NONE;
+                if (found) rec = nb[((size_t)b << kshift) + gl];
+                if (found && gl == 0) {                                   // slot 0 is b itself
+#pragma unroll
+                    for (int k = 0; k < DVP; k++)
+                        if (rec.chk[k] != NONE) atomicXor(&S32[rec.chk[k] >> 5], 1u << (rec.chk[k] & 31));   // flip.rs:29
+                    O32[b >> 5] ^= 1u << (b & 31);                        // flip.rs:30
+                }
+                wave_sync();
+                uint32_t minset = NONE;
+                for (uint32_t r = 0; r < K; r += 16) {
+                    if (found) {
+                        if (r) rec = nb[((size_t)b << kshift) + r + gl];
+                        if (rec.bit != NONE) {
+                            const uint32_t bitm = 1u << (rec.bit & 31);
+                            if (rec_flippable<DVP>(rec, S32)) {
+                                atomicOr(&F32[rec.bit >> 5], bitm);
+                                minset = rec.bit < minset ? rec.bit : minset;
+                            } else {
+                                atomicAnd(&F32[rec.bit >> 5], ~bitm);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+                    const uint32_t o = __shfl_xor(minset, off, 16);
+                    minset = o < minset ? o : minset;
+                }
+                if (found) {
+                    nfl++;
+                    const uint32_t bw = cur + l, mw = minset == NONE ? NONE : minset >> 6;
+                    cur = mw < bw ? mw : bw;
+                }
+                wave_sync();
+            }
+            // ---------------------------------------------------------------- failure test + outputs
+            for (uint32_t j = 0; j < nvalid; j++) {
+                const uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Wm + Wn;
+                const uint64_t i = base + j;
+                uint64_t anyo = 0, anys = 0;
+                for (uint32_t w = lane; w < Wn; w += 64) {
+                    const uint64_t x = Oj[w];
+                    anyo |= x;
+                    if (a.words_out) a.words_out[i * Wn + w] = x;
+                }
+                for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
+                const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
+                const uint32_t nf = __shfl(nfl, j * 16, 64);
+                if (a.flips_out && lane == 0) a.flips_out[i] = nf;
+                c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nf;
+            }
+            wave_sync();
+        }
     }
     if (lane == 0 && a.counters) {
         atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
@@ -569,6 +780,24 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(flip_kernel, dim3(grid_for(a.n_shots, wpb, 256 * 8)), dim3(wpb * 64), lds, st, g, a);
+    return hipGetLastError();
+}
+
+size_t flip2_lds_bytes(const DeviceGraph &g)
+{
+    size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    return (FLIP2_HDR + 4 * (Wm + 2 * Wn)) * 8;
+}
+
+hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    const size_t lds = flip2_lds_bytes(g);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / lds);
+    uint32_t grid = grid_for(a.n_shots, 4, 256 * per_cu);
+    if (nb.dvp == 3) hipLaunchKernelGGL(flip2_kernel<3>, dim3(grid), dim3(64), lds, st, g, nb, a);
+    else hipLaunchKernelGGL(flip2_kernel<7>, dim3(grid), dim3(64), lds, st, g, nb, a);
     return hipGetLastError();
 }
 

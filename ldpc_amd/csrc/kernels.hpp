@@ -62,7 +62,18 @@ struct BpArgs {
     GapTable gap;
 };
 
+// 2-hop neighbourhood table of the flip decoder: for every bit b, K slots of
+// (bit, its checks): slot 0 is b itself, the others are the bits that share a
+// check with b.  One flip touches exactly these bits, so one contiguous
+// K*(1+dvp)*4-byte read per flip replaces the H^T -> H -> H^T pointer chase.
+struct NbTable {
+    const uint32_t *rec;   // [n][K][1 + dvp] u32, unused entries 0xFFFFFFFF
+    uint32_t kshift;       // K = 1 << kshift, K >= 16
+    uint32_t dvp;          // checks per slot: 3 or 7
+};
+
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
+size_t flip2_lds_bytes(const DeviceGraph &g);
 
 hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
                              uint64_t *d_words, hipStream_t st);
@@ -71,6 +82,7 @@ hipError_t launch_sample_depol(const GapTable &gap, uint32_t n, uint64_t seed, u
 hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_t *d_words, uint64_t *d_synd,
                            hipStream_t st);
 hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st);
+hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st);
 hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, hipStream_t st);
 // counters[FAILURES] += #{flags != 0}, [XFAIL] += #{flags & 1}, [ZFAIL] += #{flags & 2}
 hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
