@@ -183,7 +183,7 @@ struct ldpc_css_code {
 struct ldpc_flip_decoder {
     ldpc_code code;
     std::mutex mu;
-    DeviceBuffer counters, nb;
+    DeviceBuffer counters, nb, o_scratch;
     NbTable nbt{};
     int path = 0;   // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel
 };
@@ -297,6 +297,8 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
     st = zero_counters(dec->counters);
     if (st) return st;
     a.counters = dec->counters.as<unsigned long long>();
+    a.max_flips = 0xFFFFFFFFu;
+    if (const char *mf = std::getenv("LDPC_HIP_FLIP_MAXFLIPS")) a.max_flips = (uint32_t)std::strtoul(mf, nullptr, 10);   // profiling aid
     const DeviceGraph &g = dec->code.dg;
     if (dec->path == 0) {
         dec->path = 1;
@@ -315,6 +317,10 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         }
     }
     if (dec->path == 2) {
+        if (!a.words_out) {
+            HIP_TRY(dec->o_scratch.reserve((size_t)flip2_max_blocks(g) * 4 * std::max<size_t>(words_for(g.n), 1) * 8));
+            a.o_scratch = dec->o_scratch.as<uint64_t>();
+        }
         KernelTimer timer;
         HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
         timer.stop_and_store();

@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
 // check and cannot be flippable).
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr uint32_t LIST_CAP = 1024;          // u16 entries; a 16-word sub-round never exceeds it
-constexpr uint32_t FLIP2_HDR = 33 + LIST_CAP / 4 + 1;   // u64 words: gap table, list, list counter
+constexpr uint32_t LIST_CAP = 512;           // u32 error positions of one shot (8 words never exceed it)
+constexpr uint32_t FLIP2_HDR = 33 + LIST_CAP / 2 + 1;   // u64 words: gap table, list, list counter
 
 template <int DVP> struct alignas(16) NbRec {
     uint32_t bit;
@@ -281,34 +281,54 @@ template <int DVP> struct alignas(16) NbRec {
 
 template <int DVP> __device__ inline bool rec_flippable(const NbRec<DVP> &r, const uint32_t *S32)
 {
+    // all S reads are issued back to back (one LDS wait), then reduced
+    uint32_t word[DVP];
+#pragma unroll
+    for (int k = 0; k < DVP; k++) word[k] = S32[r.chk[k] != NONE ? (r.chk[k] >> 5) : 0];
     uint32_t deg = 0, unsat = 0;
 #pragma unroll
     for (int k = 0; k < DVP; k++) {
-        const uint32_t c = r.chk[k];
-        const bool valid = c != NONE;
-        const uint32_t word = S32[valid ? (c >> 5) : 0];
+        const uint32_t valid = r.chk[k] != NONE ? 1u : 0u;
         deg += valid;
-        unsat += valid ? ((word >> (c & 31)) & 1u) : 0u;
+        unsat += valid & (word[k] >> (r.chk[k] & 31));
     }
     return unsat > deg / 2;   // flip.rs:41
 }
 
-__device__ inline uint32_t wave_sum32(uint32_t x)
+// Orders one wave's LDS traffic for the compiler only: the LDS pipeline executes a
+// wave's instructions in issue order, so a later read sees an earlier atomic of
+// another lane of the same wave without waiting for it to retire.
+__device__ inline void wave_order()
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DVP> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
+// minimum over each row of 16 lanes (DPP row rotations: no LDS round trip)
+__device__ inline uint32_t row_min_u32(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    v = o < v ? o : v;
+    return v;
+}
+
+template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
     const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    const uint32_t per_shot = Wm + 2 * Wn;
+    const uint32_t per_shot = Wm + Wn;               // LDS words per shot: S and F (O lives in HBM)
     uint32_t *q = (uint32_t *)lds;
-    uint16_t *list = (uint16_t *)(lds + 33);
-    uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 4);
+    uint32_t *list = (uint32_t *)(lds + 33);         // error positions of the shot being set up
+    uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 2);
     uint64_t *state = lds + FLIP2_HDR;
     const NbRec<DVP> *nb = (const NbRec<DVP> *)nbt.rec;
     const uint32_t kshift = nbt.kshift, K = 1u << kshift;
@@ -320,12 +340,20 @@ template <int DVP> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGrap
 
     for (uint64_t base = (uint64_t)blockIdx.x * 4; base < a.n_shots; base += (uint64_t)gridDim.x * 4) {
         const uint32_t nvalid = a.n_shots - base < 4 ? (uint32_t)(a.n_shots - base) : 4u;
-        // ------------------------------------------------------------------ set-up
+        // output word of shot j: the caller's buffer, or this block's scratch slice
+        auto out_words = [&](uint32_t j) -> uint64_t * {
+            return a.words_out ? a.words_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * 4 + j) * Wn;
+        };
+        // ------------------------------------------------------------------ set-up, wave-wide, shot by shot
         for (uint32_t j = 0; j < nvalid; j++) {
-            uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = F + Wn;
+            uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = out_words(j);
             uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
             const uint64_t i = base + j, shot = a.first_shot + i;
             for (uint32_t w = lane; w < Wm; w += 64) S[w] = 0;
+            for (uint32_t w = lane; w < Wn; w += 64) F[w] = 0;
+            if (lane == 0) *cnt_lds = 0;
+            wave_order();
+            // noise (or the caller's word); error positions go to the LDS list as they appear
             for (uint32_t w = lane; w < Wn; w += 64) {
                 const uint32_t nb_bits = bits_in_word(g.n, w);
                 uint64_t x;
@@ -334,122 +362,144 @@ template <int DVP> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGrap
                     x = a.words_in[i * Wn + w];
                     if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
                 }
-                F[w] = 0;
                 O[w] = x;
                 if (a.errors_out) a.errors_out[i * Wn + w] = x;
+                const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+                if (cc) {
+                    uint32_t off = atomicAdd(cnt_lds, cc);
+                    while (x) {
+                        if (off < LIST_CAP) list[off] = (w << 6) + (uint32_t)__builtin_ctzll(x);
+                        off++;
+                        x &= x - 1;
+                    }
+                }
             }
-            wave_sync();
-            for (int pass = 0; pass < 2; pass++) {
-                for (uint32_t wb = 0; wb < Wn; wb += 64) {
-                    const uint32_t w = wb + lane;
-                    const uint64_t x = w < Wn ? O[w] : 0;
-                    const uint32_t total = wave_sum32((uint32_t)__builtin_popcountll(x));
-                    if (total == 0) continue;
-                    const uint32_t nsub = total <= LIST_CAP ? 1u : 4u;
-                    for (uint32_t sub = 0; sub < nsub; sub++) {
+            wave_sync();   // O is read back from memory below (overflow path) and at the end
+            const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
+            if (total <= LIST_CAP) {
+                // pass 1, syndrome: toggle the checks of every error bit (slot 0 of its row)
+                for (uint32_t t = lane; t < total; t += 64) {
+                    const NbRec<DVP> r = nb[(size_t)list[t] << kshift];
+#pragma unroll
+                    for (int k = 0; k < DVP; k++)
+                        if (r.chk[k] != NONE) atomicXor(&S32[r.chk[k] >> 5], 1u << (r.chk[k] & 31));
+                }
+                wave_order();
+                // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
+                for (uint32_t t = lane; t < (total << kshift); t += 64) {
+                    const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
+                    if (r.bit != NONE && rec_flippable<DVP>(r, S32)) atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                }
+            } else {
+                // more errors than the list holds (large p): same two passes over 16-word pieces of the
+                // word, each piece (<= 1024 positions) listed in turn
+                for (int pass = 0; pass < 2; pass++) {
+                    for (uint32_t wb = 0; wb < Wn; wb += 8) {
+                        wave_order();
                         if (lane == 0) *cnt_lds = 0;
-                        wave_sync();
-                        uint64_t xx = (nsub == 1 || grp == sub) ? x : 0;
-                        const uint32_t cc = (uint32_t)__builtin_popcountll(xx);
-                        uint32_t off = cc ? atomicAdd(cnt_lds, cc) : 0;
-                        while (xx) {
-                            list[off++] = (uint16_t)(lane * 64 + (uint32_t)__builtin_ctzll(xx));
-                            xx &= xx - 1;
+                        wave_order();
+                        const uint32_t w = wb + lane;
+                        uint64_t x = (lane < 8 && w < Wn) ? O[w] : 0;
+                        const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+                        if (cc) {
+                            uint32_t off = atomicAdd(cnt_lds, cc);
+                            while (x) {
+                                list[off++] = (w << 6) + (uint32_t)__builtin_ctzll(x);
+                                x &= x - 1;
+                            }
                         }
-                        wave_sync();
+                        wave_order();
                         const uint32_t cnt = __builtin_amdgcn_readfirstlane(*cnt_lds);
                         if (pass == 0) {
-                            // syndrome: toggle the checks of every error bit (slot 0 of its row)
                             for (uint32_t t = lane; t < cnt; t += 64) {
-                                const uint32_t e = wb * 64 + list[t];
-                                const NbRec<DVP> r = nb[(size_t)e << kshift];
+                                const NbRec<DVP> r = nb[(size_t)list[t] << kshift];
 #pragma unroll
                                 for (int k = 0; k < DVP; k++)
                                     if (r.chk[k] != NONE) atomicXor(&S32[r.chk[k] >> 5], 1u << (r.chk[k] & 31));
                             }
                         } else {
-                            // flippable mask: only bits next to an error bit can see an unsatisfied check
                             for (uint32_t t = lane; t < (cnt << kshift); t += 64) {
-                                const uint32_t e = wb * 64 + list[t >> kshift];
-                                const NbRec<DVP> r = nb[((size_t)e << kshift) + (t & (K - 1))];
+                                const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
                                 if (r.bit != NONE && rec_flippable<DVP>(r, S32)) atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
                             }
                         }
-                        wave_sync();
                     }
+                    wave_order();
                 }
-                if (pass == 0 && a.synd_out)
-                    for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
             }
+            wave_order();
+            if (a.synd_out)
+                for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
         }
         // ------------------------------------------------------------------ serial flips, 4 shots in lockstep
         {
-            uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm, *O = F + Wn;
-            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *O32 = (uint32_t *)O;
+            uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm;
+            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
+            uint32_t *O32 = (uint32_t *)out_words(grp < nvalid ? grp : 0);
             bool active = grp < nvalid;
             uint32_t cur = 0, nfl = 0;   // invariant: no flippable bit below word `cur`
+            const uint32_t max_flips = a.max_flips;
             while (__ballot(active)) {
+                // lowest flippable bit of the shot: each lane proposes the first set bit of its
+                // word of the 16-word window, the row of 16 lanes takes the minimum
                 const uint32_t w = cur + gl;
                 const uint64_t x = (active && w < Wn) ? F[w] : 0;
-                const uint64_t nz = __ballot(x != 0);
-                const uint32_t gm = (uint32_t)(nz >> (grp * 16)) & 0xFFFFu;
-                const bool found = active && gm != 0;
+                uint32_t cand = x ? (w << 6) + (uint32_t)__builtin_ctzll(x) : NONE;
+                cand = row_min_u32(cand);
+                const bool found = active && cand != NONE;
                 if (active && !found) {
                     cur += 16;
                     if (cur >= Wn) active = false;                      // flip.rs:27 find_flippable == None
                 }
-                const uint32_t l = found ? (uint32_t)__builtin_ctz(gm) : 0u;
-                const uint32_t src = (grp << 4) + l;
-                const uint32_t xlo = __shfl((uint32_t)x, src, 64), xhi = __shfl((uint32_t)(x >> 32), src, 64);
-                const uint64_t xw = ((uint64_t)xhi << 32) | xlo;
-                const uint32_t b = found ? (cur + l) * 64 + (uint32_t)__builtin_ctzll(xw) : 0u;
-                NbRec<DVP> rec;
-                rec.bit = NONE;
-                if (found) rec = nb[((size_t)b << kshift) + gl];
-                if (found && gl == 0) {                                   // slot 0 is b itself
-#pragma unroll
-                    for (int k = 0; k < DVP; k++)
-                        if (rec.chk[k] != NONE) atomicXor(&S32[rec.chk[k] >> 5], 1u << (rec.chk[k] & 31));   // flip.rs:29
-                    O32[b >> 5] ^= 1u << (b & 31);                        // flip.rs:30
-                }
-                wave_sync();
+                const uint32_t b = found ? cand : 0u;
                 uint32_t minset = NONE;
                 for (uint32_t r = 0; r < K; r += 16) {
-                    if (found) {
-                        if (r) rec = nb[((size_t)b << kshift) + r + gl];
-                        if (rec.bit != NONE) {
-                            const uint32_t bitm = 1u << (rec.bit & 31);
-                            if (rec_flippable<DVP>(rec, S32)) {
-                                atomicOr(&F32[rec.bit >> 5], bitm);
-                                minset = rec.bit < minset ? rec.bit : minset;
-                            } else {
-                                atomicAnd(&F32[rec.bit >> 5], ~bitm);
+                    NbRec<DVP> rec;
+                    rec.bit = NONE;
+#pragma unroll
+                    for (int k = 0; k < DVP; k++) rec.chk[k] = NONE;
+                    if (found) rec = nb[((size_t)b << kshift) + r + gl];
+                    if (r == 0) {
+                        // slot 0 (lane 0 of the row) is b itself: syndrome ^= H e_b (flip.rs:28-29)
+                        if (found && gl == 0) {   // one lane per shot: the atomics of idle lanes would only collide
+#pragma unroll
+                            for (int k = 0; k < DVP; k++) {
+                                const bool v = rec.chk[k] != NONE;
+                                atomicXor(&S32[v ? (rec.chk[k] >> 5) : 0], v ? (1u << (rec.chk[k] & 31)) : 0u);
                             }
                         }
+                        wave_order();
                     }
+                    // every slot re-evaluates its bit against the new syndrome and fixes its F bit
+                    const bool have = rec.bit != NONE;
+                    const uint32_t fword = F32[have ? (rec.bit >> 5) : 0];
+                    const bool fl = have && rec_flippable<DVP>(rec, S32);
+                    const bool old = (fword >> (rec.bit & 31)) & 1u;
+                    if (have && fl != old) atomicXor(&F32[rec.bit >> 5], 1u << (rec.bit & 31));
+                    if (fl) minset = rec.bit < minset ? rec.bit : minset;
                 }
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {
-                    const uint32_t o = __shfl_xor(minset, off, 16);
-                    minset = o < minset ? o : minset;
-                }
+                // output ^= e_b (flip.rs:30): an L2 atomic, issued after this iteration's row has been
+                // consumed so that it retires under the next iteration's LDS work and row load
+                if (found && gl == 0)
+                    __hip_atomic_fetch_xor(&O32[b >> 5], 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                minset = row_min_u32(minset);
                 if (found) {
                     nfl++;
-                    const uint32_t bw = cur + l, mw = minset == NONE ? NONE : minset >> 6;
+                    const uint32_t bw = b >> 6, mw = minset == NONE ? NONE : minset >> 6;
                     cur = mw < bw ? mw : bw;
                 }
-                wave_sync();
+                wave_order();
+                if (DIAG && nfl >= max_flips) active = false;   // profiling aid only
             }
+            wave_sync();   // the output-word atomics have landed
             // ---------------------------------------------------------------- failure test + outputs
             for (uint32_t j = 0; j < nvalid; j++) {
-                const uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Wm + Wn;
+                const uint64_t *Sj = state + (size_t)j * per_shot;
+                uint64_t *Oj = out_words(j);
                 const uint64_t i = base + j;
                 uint64_t anyo = 0, anys = 0;
-                for (uint32_t w = lane; w < Wn; w += 64) {
-                    const uint64_t x = Oj[w];
-                    anyo |= x;
-                    if (a.words_out) a.words_out[i * Wn + w] = x;
-                }
+                for (uint32_t w = lane; w < Wn; w += 64)   // device-scope loads: the flips were applied by L2 atomics
+                    anyo |= __hip_atomic_load(&Oj[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
                 const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
                 const uint32_t nf = __shfl(nfl, j * 16, 64);
@@ -786,7 +836,13 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
 size_t flip2_lds_bytes(const DeviceGraph &g)
 {
     size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    return (FLIP2_HDR + 4 * (Wm + 2 * Wn)) * 8;
+    return (FLIP2_HDR + 4 * (Wm + Wn)) * 8;
+}
+
+uint32_t flip2_max_blocks(const DeviceGraph &g)
+{
+    // one wave per block; blocks per CU limited by LDS (160 KiB) and by 8 waves per SIMD
+    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g));
 }
 
 hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st)
@@ -794,10 +850,15 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
     if (!a.n_shots) return hipSuccess;
     const size_t lds = flip2_lds_bytes(g);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(16, (160 * 1024) / lds);
-    uint32_t grid = grid_for(a.n_shots, 4, 256 * per_cu);
-    if (nb.dvp == 3) hipLaunchKernelGGL(flip2_kernel<3>, dim3(grid), dim3(64), lds, st, g, nb, a);
-    else hipLaunchKernelGGL(flip2_kernel<7>, dim3(grid), dim3(64), lds, st, g, nb, a);
+    uint32_t grid = grid_for(a.n_shots, 4, flip2_max_blocks(g));
+    const bool diag = a.max_flips != 0xFFFFFFFFu;
+    if (nb.dvp == 3) {
+        if (diag) hipLaunchKernelGGL((flip2_kernel<3, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<3, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+    } else {
+        if (diag) hipLaunchKernelGGL((flip2_kernel<7, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<7, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+    }
     return hipGetLastError();
 }
 

@@ -32,6 +32,8 @@ struct FlipArgs {
     uint64_t *words_out;        // [n_shots][Wn]  or null: decoded word
     uint32_t *flips_out;        // [n_shots]      or null
     unsigned long long *counters;   // [LDPC_COUNTERS] device, accumulated
+    uint32_t max_flips;         // diagnostics: stop a shot after this many flips (default: unlimited)
+    uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][4][Wn] output words when words_out is null
     GapTable gap;
 };
 
@@ -74,6 +76,7 @@ struct NbTable {
 
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
 size_t flip2_lds_bytes(const DeviceGraph &g);
+uint32_t flip2_max_blocks(const DeviceGraph &g);
 
 hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
                              uint64_t *d_words, hipStream_t st);
