@@ -306,19 +306,25 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         uint32_t kshift = 0, dvp = 0;
         const char *force = std::getenv("LDPC_HIP_FLIP_KERNEL");   // "csr" forces the generic kernel (tests)
         const bool allow_fast = !(force && std::strcmp(force, "csr") == 0);
-        if (allow_fast && flip2_lds_bytes(g) <= 64 * 1024 && g.n < (1u << 26) &&
+        if (allow_fast && flip2_lds_bytes(g, 16) <= 64 * 1024 && g.n < (1u << 26) &&
             build_nb_table(dec->code.host, tab, kshift, dvp)) {
             HIP_TRY(dec->nb.reserve(std::max<size_t>(tab.size(), 1) * 4));
             if (!tab.empty()) HIP_TRY(hipMemcpy(dec->nb.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
             dec->nbt.rec = dec->nb.as<uint32_t>();
             dec->nbt.kshift = kshift;
             dec->nbt.dvp = dvp;
+            {
+                const SparseBinMat &t = dec->code.host.ht;
+                bool reg = true;
+                for (uint32_t b2 = 0; b2 < t.nrows(); b2++) reg = reg && t.row_len(b2) == dvp;
+                dec->nbt.regular = reg ? 1u : 0u;
+            }
             dec->path = 2;
         }
     }
     if (dec->path == 2) {
         if (!a.words_out) {
-            HIP_TRY(dec->o_scratch.reserve((size_t)flip2_max_blocks(g) * 4 * std::max<size_t>(words_for(g.n), 1) * 8));
+            HIP_TRY(dec->o_scratch.reserve((size_t)flip2_max_blocks(g) * 8 * std::max<size_t>(words_for(g.n), 1) * 8));
             a.o_scratch = dec->o_scratch.as<uint64_t>();
         }
         KernelTimer timer;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 
@@ -274,35 +275,57 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t LIST_CAP = 512;           // u32 error positions of one shot (8 words never exceed it)
 constexpr uint32_t FLIP2_HDR = 33 + LIST_CAP / 2 + 1;   // u64 words: gap table, list, list counter
 
+__device__ inline uint32_t row_min_u32(uint32_t v);
+__device__ inline uint32_t half_row_min_u32(uint32_t v);
+template <int G> __device__ inline uint32_t group_min_u32(uint32_t v)
+{
+    if (G == 16) return row_min_u32(v);
+    return half_row_min_u32(v);
+}
+
 template <int DVP> struct alignas(16) NbRec {
     uint32_t bit;
     uint32_t chk[DVP];
 };
 
-template <int DVP> __device__ inline bool rec_flippable(const NbRec<DVP> &r, const uint32_t *S32)
+template <int DVP, bool REG> __device__ inline bool rec_flippable(const NbRec<DVP> &r, const uint32_t *S32)
 {
-    // all S reads are issued back to back (one LDS wait), then reduced
+    // all S reads are issued back to back (one LDS wait), then reduced.  REG: every bit has
+    // exactly DVP checks, no sentinel tests.
     uint32_t word[DVP];
 #pragma unroll
-    for (int k = 0; k < DVP; k++) word[k] = S32[r.chk[k] != NONE ? (r.chk[k] >> 5) : 0];
+    for (int k = 0; k < DVP; k++) word[k] = S32[(REG || r.chk[k] != NONE) ? (r.chk[k] >> 5) : 0];
     uint32_t deg = 0, unsat = 0;
 #pragma unroll
     for (int k = 0; k < DVP; k++) {
-        const uint32_t valid = r.chk[k] != NONE ? 1u : 0u;
+        const uint32_t valid = (REG || r.chk[k] != NONE) ? 1u : 0u;
         deg += valid;
         unsat += valid & (word[k] >> (r.chk[k] & 31));
     }
     return unsat > deg / 2;   // flip.rs:41
 }
 
-// Orders one wave's LDS traffic for the compiler only: the LDS pipeline executes a
-// wave's instructions in issue order, so a later read sees an earlier atomic of
-// another lane of the same wave without waiting for it to retire.
+// Orders one wave's LDS traffic (wavefront-scope fence: no cache action, no wait for
+// retirement): the LDS pipeline executes a wave's instructions in issue order, so a
+// later read sees an earlier atomic of another lane of the same wave.
 __device__ inline void wave_order()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// minimum over each group of 8 lanes: xor-1 and xor-2 quad permutes, then the half-row mirror
+__device__ inline uint32_t half_row_min_u32(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm:[1,0,3,2]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm:[2,3,0,1]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v = o < v ? o : v;
+    return v;
 }
 
 // minimum over each row of 16 lanes (DPP row rotations: no LDS round trip)
@@ -320,12 +343,14 @@ __device__ inline uint32_t row_min_u32(uint32_t v)
     return v;
 }
 
-template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
+template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
-    const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15;
+    constexpr uint32_t SPW = 64 / G;                 // shots per wave
+    const uint32_t lane = threadIdx.x, grp = lane / G, gl = lane % G;
     const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    const uint32_t per_shot = Wm + Wn;               // LDS words per shot: S and F (O lives in HBM)
+    const uint32_t WS = (Wn + 63) / 64;              // summary words: bit w of FS set if F[w] may be non-zero
+    const uint32_t per_shot = Wm + Wn + WS;          // LDS words per shot: S, F, FS (O lives in HBM)
     uint32_t *q = (uint32_t *)lds;
     uint32_t *list = (uint32_t *)(lds + 33);         // error positions of the shot being set up
     uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 2);
@@ -336,21 +361,21 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
     for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
     wave_sync();
 
-    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0, c_iters = 0;
 
-    for (uint64_t base = (uint64_t)blockIdx.x * 4; base < a.n_shots; base += (uint64_t)gridDim.x * 4) {
-        const uint32_t nvalid = a.n_shots - base < 4 ? (uint32_t)(a.n_shots - base) : 4u;
+    for (uint64_t base = (uint64_t)blockIdx.x * SPW; base < a.n_shots; base += (uint64_t)gridDim.x * SPW) {
+        const uint32_t nvalid = a.n_shots - base < SPW ? (uint32_t)(a.n_shots - base) : SPW;
         // output word of shot j: the caller's buffer, or this block's scratch slice
         auto out_words = [&](uint32_t j) -> uint64_t * {
-            return a.words_out ? a.words_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * 4 + j) * Wn;
+            return a.words_out ? a.words_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * SPW + j) * Wn;
         };
         // ------------------------------------------------------------------ set-up, wave-wide, shot by shot
         for (uint32_t j = 0; j < nvalid; j++) {
             uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = out_words(j);
-            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
+            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *FS32 = (uint32_t *)(F + Wn);
             const uint64_t i = base + j, shot = a.first_shot + i;
             for (uint32_t w = lane; w < Wm; w += 64) S[w] = 0;
-            for (uint32_t w = lane; w < Wn; w += 64) F[w] = 0;
+            for (uint32_t w = lane; w < Wn + WS; w += 64) F[w] = 0;   // F and its summary FS
             if (lane == 0) *cnt_lds = 0;
             wave_order();
             // noise (or the caller's word); error positions go to the LDS list as they appear
@@ -388,7 +413,10 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
                 // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
                 for (uint32_t t = lane; t < (total << kshift); t += 64) {
                     const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
-                    if (r.bit != NONE && rec_flippable<DVP>(r, S32)) atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                    if (r.bit != NONE && rec_flippable<DVP, REG>(r, S32)) {
+                                    atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                                    atomicOr(&FS32[r.bit >> 11], 1u << ((r.bit >> 6) & 31));
+                                }
                 }
             } else {
                 // more errors than the list holds (large p): same two passes over 16-word pieces of the
@@ -420,7 +448,10 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
                         } else {
                             for (uint32_t t = lane; t < (cnt << kshift); t += 64) {
                                 const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
-                                if (r.bit != NONE && rec_flippable<DVP>(r, S32)) atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                                if (r.bit != NONE && rec_flippable<DVP, REG>(r, S32)) {
+                                    atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
+                                    atomicOr(&FS32[r.bit >> 11], 1u << ((r.bit >> 6) & 31));
+                                }
                             }
                         }
                     }
@@ -431,64 +462,84 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
             if (a.synd_out)
                 for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
         }
-        // ------------------------------------------------------------------ serial flips, 4 shots in lockstep
+        // ------------------------------------------------------------------ serial flips, SPW shots in lockstep
         {
-            uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm;
-            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F;
+            uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm, *FS = F + Wn;
+            uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *FS32 = (uint32_t *)FS;
             uint32_t *O32 = (uint32_t *)out_words(grp < nvalid ? grp : 0);
             bool active = grp < nvalid;
-            uint32_t cur = 0, nfl = 0;   // invariant: no flippable bit below word `cur`
+            uint32_t curS = 0, nfl = 0;   // invariant: no flippable bit in F words below 64*curS
             const uint32_t max_flips = a.max_flips;
+            const bool big = WS > G;      // otherwise one window covers the whole summary and curS stays 0
             while (__ballot(active)) {
-                // lowest flippable bit of the shot: each lane proposes the first set bit of its
-                // word of the 16-word window, the row of 16 lanes takes the minimum
-                const uint32_t w = cur + gl;
-                const uint64_t x = (active && w < Wn) ? F[w] : 0;
-                uint32_t cand = x ? (w << 6) + (uint32_t)__builtin_ctzll(x) : NONE;
-                cand = row_min_u32(cand);
-                const bool found = active && cand != NONE;
-                if (active && !found) {
-                    cur += 16;
-                    if (cur >= Wn) active = false;                      // flip.rs:27 find_flippable == None
+                // lowest flippable bit of the shot, two levels: the summary FS names the first F word that may
+                // be non-zero (each lane looks at one summary word, the group takes the minimum), then that
+                // F word gives the bit.  A summary bit can be stale (set, word empty): it is cleared and the
+                // iteration does nothing else.
+                const uint32_t sw = curS + gl;
+                const uint64_t fs = (active && sw < WS) ? FS[sw] : 0;
+                uint32_t candw = fs ? (sw << 6) + (uint32_t)__builtin_ctzll(fs) : NONE;
+                candw = group_min_u32<G>(candw);
+                const bool havew = active && candw != NONE;
+                if (active && !havew) {
+                    curS += G;
+                    if (curS >= WS) active = false;                     // flip.rs:27 find_flippable == None
                 }
-                const uint32_t b = found ? cand : 0u;
+                const uint64_t x = havew ? F[candw] : 0;
+                const bool found = havew && x != 0;
+                if (havew && !found && gl == 0) atomicAnd(&FS32[candw >> 5], ~(1u << (candw & 31)));
+                const uint32_t b = found ? (candw << 6) + (uint32_t)__builtin_ctzll(x) : 0u;
                 uint32_t minset = NONE;
-                for (uint32_t r = 0; r < K; r += 16) {
-                    NbRec<DVP> rec;
-                    rec.bit = NONE;
+                NbRec<DVP> rec_next;
+                rec_next.bit = NONE;
 #pragma unroll
-                    for (int k = 0; k < DVP; k++) rec.chk[k] = NONE;
-                    if (found) rec = nb[((size_t)b << kshift) + r + gl];
+                for (int k = 0; k < DVP; k++) rec_next.chk[k] = NONE;
+                if (found) rec_next = nb[((size_t)b << kshift) + gl];
+                for (uint32_t r = 0; r < K; r += G) {
+                    const NbRec<DVP> rec = rec_next;
+                    if (r + G < K && found) rec_next = nb[((size_t)b << kshift) + r + G + gl];   // next round's slots in flight
                     if (r == 0) {
-                        // slot 0 (lane 0 of the row) is b itself: syndrome ^= H e_b (flip.rs:28-29)
+                        // slot 0 (lane 0 of the group) is b itself: syndrome ^= H e_b (flip.rs:28-29)
                         if (found && gl == 0) {   // one lane per shot: the atomics of idle lanes would only collide
 #pragma unroll
                             for (int k = 0; k < DVP; k++) {
-                                const bool v = rec.chk[k] != NONE;
-                                atomicXor(&S32[v ? (rec.chk[k] >> 5) : 0], v ? (1u << (rec.chk[k] & 31)) : 0u);
+                                if (REG) atomicXor(&S32[rec.chk[k] >> 5], 1u << (rec.chk[k] & 31));
+                                else {
+                                    const bool v = rec.chk[k] != NONE;
+                                    atomicXor(&S32[v ? (rec.chk[k] >> 5) : 0], v ? (1u << (rec.chk[k] & 31)) : 0u);
+                                }
                             }
+                            // b was the only flippable bit of its word: the word empties (a neighbour that
+                            // becomes flippable in it sets the summary bit again below)
+                            if ((x & (x - 1)) == 0) atomicAnd(&FS32[candw >> 5], ~(1u << (candw & 31)));
                         }
                         wave_order();
                     }
                     // every slot re-evaluates its bit against the new syndrome and fixes its F bit
                     const bool have = rec.bit != NONE;
                     const uint32_t fword = F32[have ? (rec.bit >> 5) : 0];
-                    const bool fl = have && rec_flippable<DVP>(rec, S32);
+                    const bool fl = have && rec_flippable<DVP, REG>(rec, S32);
                     const bool old = (fword >> (rec.bit & 31)) & 1u;
-                    if (have && fl != old) atomicXor(&F32[rec.bit >> 5], 1u << (rec.bit & 31));
-                    if (fl) minset = rec.bit < minset ? rec.bit : minset;
+                    if (have && fl != old) {
+                        atomicXor(&F32[rec.bit >> 5], 1u << (rec.bit & 31));
+                        if (fl) atomicOr(&FS32[rec.bit >> 11], 1u << ((rec.bit >> 6) & 31));
+                    }
+                    if (big && fl) minset = rec.bit < minset ? rec.bit : minset;
                 }
                 // output ^= e_b (flip.rs:30): an L2 atomic, issued after this iteration's row has been
                 // consumed so that it retires under the next iteration's LDS work and row load
                 if (found && gl == 0)
                     __hip_atomic_fetch_xor(&O32[b >> 5], 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                minset = row_min_u32(minset);
-                if (found) {
-                    nfl++;
-                    const uint32_t bw = b >> 6, mw = minset == NONE ? NONE : minset >> 6;
-                    cur = mw < bw ? mw : bw;
+                if (found) nfl++;
+                if (big) {   // more summary words than lanes: keep the scan cursor at the lowest possible word
+                    minset = group_min_u32<G>(minset);
+                    if (found) {
+                        const uint32_t bs = b >> 12, ms = minset == NONE ? NONE : minset >> 12;
+                        curS = ms < bs ? ms : bs;
+                    }
                 }
                 wave_order();
+                if (DIAG && active) c_iters++;                  // profiling aid: loop iterations incl. empty ones
                 if (DIAG && nfl >= max_flips) active = false;   // profiling aid only
             }
             wave_sync();   // the output-word atomics have landed
@@ -502,7 +553,7 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
                     anyo |= __hip_atomic_load(&Oj[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
                 const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
-                const uint32_t nf = __shfl(nfl, j * 16, 64);
+                const uint32_t nf = __shfl(nfl, j * G, 64);
                 if (a.flips_out && lane == 0) a.flips_out[i] = nf;
                 c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nf;
             }
@@ -516,6 +567,7 @@ template <int DVP, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel
         if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
         if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
     }
+    if (DIAG && a.counters && gl == 0 && c_iters) atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_iters);
 }
 
 // ---------------------------------------------------------------------------
@@ -833,31 +885,53 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t flip2_lds_bytes(const DeviceGraph &g)
+size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot)
 {
     size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    return (FLIP2_HDR + 4 * (Wm + Wn)) * 8;
+    return (FLIP2_HDR + (64 / lanes_per_shot) * (Wm + Wn + (Wn + 63) / 64)) * 8;
+}
+
+uint32_t flip2_lanes_per_shot(const DeviceGraph &g)
+{
+    // 8 lanes per shot (8 shots per wave) halves the instructions per shot; needs 8 states in LDS
+    // (measured at C2: 16 lanes x 4 shots beats 8 x 8: one round per flip, twice the waves in flight)
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_LANES")) return std::atoi(e) == 8 ? 8u : 16u;   // A/B aid
+    return 16u;
 }
 
 uint32_t flip2_max_blocks(const DeviceGraph &g)
 {
     // one wave per block; blocks per CU limited by LDS (160 KiB) and by 8 waves per SIMD
-    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g));
+    const uint32_t lanes = flip2_lanes_per_shot(g);
+    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g, lanes));
+}
+
+template <int DVP, int G>
+static void launch_flip2_t(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, uint32_t grid, size_t lds, hipStream_t st)
+{
+    const bool diag = a.max_flips != 0xFFFFFFFFu;
+    if (nb.regular) {
+        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+    } else {
+        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+    }
 }
 
 hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
-    const size_t lds = flip2_lds_bytes(g);
+    const uint32_t lanes = flip2_lanes_per_shot(g);
+    const size_t lds = flip2_lds_bytes(g, lanes);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    uint32_t grid = grid_for(a.n_shots, 4, flip2_max_blocks(g));
-    const bool diag = a.max_flips != 0xFFFFFFFFu;
+    const uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_max_blocks(g));
     if (nb.dvp == 3) {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<3, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<3, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (lanes == 8) launch_flip2_t<3, 8>(g, nb, a, grid, lds, st);
+        else launch_flip2_t<3, 16>(g, nb, a, grid, lds, st);
     } else {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<7, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<7, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (lanes == 8) launch_flip2_t<7, 8>(g, nb, a, grid, lds, st);
+        else launch_flip2_t<7, 16>(g, nb, a, grid, lds, st);
     }
     return hipGetLastError();
 }

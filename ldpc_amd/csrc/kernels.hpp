@@ -33,7 +33,7 @@ struct FlipArgs {
     uint32_t *flips_out;        // [n_shots]      or null
     unsigned long long *counters;   // [LDPC_COUNTERS] device, accumulated
     uint32_t max_flips;         // diagnostics: stop a shot after this many flips (default: unlimited)
-    uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][4][Wn] output words when words_out is null
+    uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][shots per wave][Wn] output words when words_out is null
     GapTable gap;
 };
 
@@ -72,10 +72,12 @@ struct NbTable {
     const uint32_t *rec;   // [n][K][1 + dvp] u32, unused entries 0xFFFFFFFF
     uint32_t kshift;       // K = 1 << kshift, K >= 16
     uint32_t dvp;          // checks per slot: 3 or 7
+    uint32_t regular;      // every bit has exactly dvp checks (no sentinels among a valid slot's checks)
 };
 
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
-size_t flip2_lds_bytes(const DeviceGraph &g);
+size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot);
+uint32_t flip2_lanes_per_shot(const DeviceGraph &g);
 uint32_t flip2_max_blocks(const DeviceGraph &g);
 
 hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
