@@ -194,7 +194,7 @@ struct ldpc_bp_decoder {
     uint32_t max_iter = 0;
     std::mutex mu;
     DeviceBuffer counters, workspace;
-    uint32_t groups_allocated = 0;
+    int reg_dc = 0, reg_dv = 0;   // common check / bit degree when the code is regular, else 0
 };
 
 struct ldpc_css_bp_decoder {
@@ -238,8 +238,9 @@ int read_counters(DeviceBuffer &d, uint64_t *out)
 
 int zero_counters(DeviceBuffer &d)
 {
-    HIP_TRY(d.reserve(sizeof(unsigned long long) * LDPC_COUNTERS));
-    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * LDPC_COUNTERS, g_stream));
+    // LDPC_COUNTERS counters followed by one work-queue word (bp_kernel)
+    HIP_TRY(d.reserve(sizeof(unsigned long long) * (LDPC_COUNTERS + 1)));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * (LDPC_COUNTERS + 1), g_stream));
     return LDPC_OK;
 }
 
@@ -375,18 +376,23 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         if (counters_out) return read_counters(dec->counters, counters_out);
         return LDPC_OK;
     }
-    // shot groups: one wave of 64 slots each; bounded by memory and by what fills the chip
+    // shot groups of 64 slots, one workgroup each.  Waves per group grow with the code (an iteration of
+    // a 64-shot group costs ~E row updates: split over up to 16 waves so that a straggler shot does not
+    // hold a multi-millisecond iteration on one wave); groups are bounded by memory and by what fills
+    // the chip (~16 waves per CU).
     size_t per_group = bp_workspace_bytes_per_group(g);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.6), (size_t)96 << 30);
-    uint64_t max_groups = std::min<uint64_t>(4096, budget / std::max<size_t>(per_group, 1));
+    uint32_t waves = 1;
+    while (waves < 16 && (size_t)g.E > (size_t)4096 * waves) waves *= 2;
+    if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(16, std::atoi(e)));   // A/B aid
+    uint64_t max_groups = std::min<uint64_t>(4096 / waves, budget / std::max<size_t>(per_group, 1));
     if (max_groups == 0)
         return fail(LDPC_ERR_CAPACITY, "bp decoder: one shot group needs " + std::to_string(per_group) +
                                            " bytes of message storage, more than the device can give");
     uint64_t groups = std::min<uint64_t>(max_groups, (r.n_shots + 63) / 64);
     groups = std::max<uint64_t>(groups, 1);
-    uint64_t quota = (r.n_shots + groups - 1) / groups;
     HIP_TRY(dec->workspace.reserve(per_group * groups));
 
     BpArgs a{};
@@ -399,7 +405,6 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.seed = r.seed;
     a.first_shot = r.first_shot;
     a.n_shots = r.n_shots;
-    a.quota = quota;
     a.words_in = r.words_in;
     a.synd_in = r.synd_in;
     a.corr_out = r.corr_out;
@@ -407,6 +412,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.post_out = r.post_out;
     a.failed_out = r.failed_out;
     a.counters = dec->counters.as<unsigned long long>();
+    a.queue = dec->counters.as<unsigned long long>() + LDPC_COUNTERS;   // zeroed with the counters
     if (r.logicals) {
         a.l_rows = r.logicals->dg.m;
         a.l_ptr = r.logicals->dg.h_ptr;
@@ -426,7 +432,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.gap = r.gap;
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);
-    HIP_TRY(launch_bp(g, a, (uint32_t)groups, g_stream));
+    HIP_TRY(launch_bp(g, a, (uint32_t)groups, waves, dec->reg_dc, dec->reg_dv, g_stream));
     if (timer) timer->stop_and_store();
     if (counters_out) return read_counters(dec->counters, counters_out);
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -438,6 +444,16 @@ int init_bp(ldpc_bp_decoder *d, const LinearCode &code, double p, size_t max_ite
     if (!valid_probability(p)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     if (max_iterations > 0xFFFFFFFFull) return fail(LDPC_ERR_BAD_ARG, "max_iterations too large");
     copy_code(d->code, code);
+    {
+        const SparseBinMat &h = d->code.host.h, &t = d->code.host.ht;
+        int dc = h.nrows() ? (int)h.row_len(0) : 0, dv = t.nrows() ? (int)t.row_len(0) : 0;
+        for (uint32_t r = 0; r < h.nrows(); r++)
+            if ((int)h.row_len(r) != dc) dc = 0;
+        for (uint32_t r = 0; r < t.nrows(); r++)
+            if ((int)t.row_len(r) != dv) dv = 0;
+        d->reg_dc = dc;
+        d->reg_dv = dv;
+    }
     d->p = p;
     d->max_iter = (uint32_t)max_iterations;
     return LDPC_OK;

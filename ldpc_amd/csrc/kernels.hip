@@ -571,22 +571,31 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
 }
 
 // ---------------------------------------------------------------------------
-// Belief propagation.  One wave owns a group of 64 shot slots, lane = slot.
-// Messages are laid out [edge][slot] (f64) in check-major edge order, so every
-// message access of the wave is one coalesced 512-byte row and every graph
-// index is wave-uniform.  A slot whose shot stops (syndrome matched or
-// iteration cap) is harvested and refilled with the group's next shot.
+// Belief propagation.  One workgroup of NW waves owns a group of 64 shot slots;
+// in every wave lane = slot = shot.  Messages are laid out [edge][slot] (f64) in
+// check-major edge order, so every message access of a wave is one coalesced
+// 512-byte row and every graph index is wave-uniform.  The waves of the group
+// split the checks (update_checks), the 64-bit chunks of bits (update_bits) and
+// the words of the set-up between them and meet at workgroup barriers; the
+// per-slot control state (active, iteration, shot id) is replicated in every
+// wave and evolves identically.  A slot whose shot stops (syndrome matched or
+// iteration cap) is harvested and refilled from a device-wide shot queue.
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 
 // f64::atanh of the reference's toolchain: 0.5 * ln_1p(2x / (1 - x))
 __device__ inline double ref_atanh(double x) { return 0.5 * log1p((2.0 * x) / (1.0 - x)); }
 
-__global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
+// DC / DV > 0: every check has exactly DC bits / every bit exactly DV checks (regular code):
+// rows start at c*DC, loops are fully unrolled and the DC (DV) independent tanh / log1p chains of
+// a row interleave.  0 = any degrees (row pointers, runtime trip counts).
+template <int DC, int DV> __global__ __launch_bounds__(1024) void bp_kernel(DeviceGraph g, BpArgs a)
 {
     __shared__ uint32_t q[65];
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
+    __shared__ unsigned long long sh_queue, sh_mism;
+    __shared__ uint32_t sh_flag[2][64];   // per slot: [0] residual non-zero, [1] a logical generator anticommutes
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6, NT = blockDim.x;
+    for (uint32_t i = tid; i < 65; i += NT) q[i] = a.gap.q[i];
     __syncthreads();
     const uint32_t n = g.n, m = g.m;
     const uint32_t Wn = (n + 63) / 64, Wm = (m + 63) / 64;
@@ -599,28 +608,33 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
     uint64_t *ssl = a.ssl + grp * (size_t)m;
     const double prior = a.prior;
 
-    uint64_t next = grp * a.quota;
-    uint64_t end = next + a.quota < a.n_shots ? next + a.quota : a.n_shots;
-    if (next > end) next = end;
-
-    bool active = false, fresh = false;
+    // replicated per-slot state (identical in all waves of the group)
+    bool drained = false, active = false, fresh = false;
     uint32_t iter = 0;
     uint64_t myi = 0;
-    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;   // accumulated by wave 0 only
 
     for (;;) {
-        // ---- refill idle slots with the group's next shots -------------------
+        // ---- refill idle slots from the device-wide queue (a.queue = shots handed out so far) ----
         {
-            uint64_t idle = __ballot(!active);
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
-            bool take = !active && (uint64_t)rank < end - next;
-            uint64_t takemask = __ballot(take);
+            const uint64_t idle = __ballot(!active);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+            uint64_t first_taken = a.n_shots;
+            if (idle && !drained) {
+                if (tid == 0) sh_queue = atomicAdd(a.queue, (unsigned long long)__builtin_popcountll(idle));
+                __syncthreads();
+                first_taken = sh_queue;
+                __syncthreads();
+                if (first_taken >= a.n_shots) { first_taken = a.n_shots; drained = true; }
+            }
+            const bool take = !active && first_taken + rank < a.n_shots;
+            const uint64_t takemask = __ballot(take);
             if (takemask) {
-                if (take) { myi = next + rank; active = true; fresh = true; iter = 0; }
-                next += (uint64_t)__builtin_popcountll(takemask);
+                if (take) { myi = first_taken + rank; active = true; fresh = true; iter = 0; }
+                if (first_taken + (uint64_t)__builtin_popcountll(idle) >= a.n_shots) drained = true;
                 const uint64_t shot = a.first_shot + myi;
                 if (a.source != SRC_SYNDROMES) {
-                    for (uint32_t w = 0; w < Wn; w++) {
+                    for (uint32_t w = wv; w < Wn; w += NW) {
                         if (take) {
                             uint32_t nb = bits_in_word(n, w);
                             uint64_t x;
@@ -636,7 +650,8 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
                             ew[(size_t)w * 64 + lane] = x;
                         }
                     }
-                    for (uint32_t c = 0; c < m; c++) {
+                    __syncthreads();
+                    for (uint32_t c = wv; c < m; c += NW) {
                         uint32_t par = 0;
                         const uint32_t e0 = g.h_ptr[c], e1 = g.h_ptr[c + 1];
                         for (uint32_t e = e0; e < e1; e++) {
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
                         if (lane == 0) ssl[c] = (ssl[c] & ~takemask) | mask;
                     }
                 } else {
-                    for (uint32_t c = 0; c < m; c++) {
+                    for (uint32_t c = wv; c < m; c += NW) {
                         uint32_t sb = 0;
                         if (take) sb = (uint32_t)(a.synd_in[myi * Wm + (c >> 6)] >> (c & 63)) & 1u;
                         uint64_t mask = __ballot(take && sb);
@@ -656,27 +671,34 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
                 }
                 // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
                 const bool init = prior < 0.0;
-                for (uint32_t b = lane; b < n; b += 64) dsl[b] = (dsl[b] & ~takemask) | (init ? takemask : 0ull);
+                for (uint32_t b = tid; b < n; b += NT) dsl[b] = (dsl[b] & ~takemask) | (init ? takemask : 0ull);
                 if (take)
-                    for (uint32_t w = 0; w < Wn; w++) {
+                    for (uint32_t w = wv; w < Wn; w += NW) {
                         uint32_t nb = bits_in_word(n, w);
                         dw[(size_t)w * 64 + lane] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
                     }
-                wave_sync();
+                __syncthreads();
             }
         }
         const uint64_t actmask = __ballot(active);
         if (!actmask) break;
 
-        // ---- stop test (belief_propagation.rs:26-27), bit-sliced over the 64 slots:
-        // lanes split the checks, each XORs whole 64-slot words
-        uint64_t mism = 0;
-        for (uint32_t c = lane; c < m; c += 64) {
-            uint64_t x = ssl[c];
-            for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= dsl[g.h_idx[e]];
-            mism |= x;
+        // ---- stop test (belief_propagation.rs:26-27), bit-sliced over the 64 slots: the threads of
+        // the group split the checks, each XORs whole 64-slot words; partial masks are OR-ed in LDS
+        if (tid == 0) sh_mism = 0;
+        __syncthreads();
+        {
+            uint64_t part = 0;
+            for (uint32_t c = tid; c < m; c += NT) {
+                uint64_t x = ssl[c];
+                for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= dsl[g.h_idx[e]];
+                part |= x;
+            }
+            part = wave_or64(part);
+            if (lane == 0 && part) atomicOr(&sh_mism, (unsigned long long)part);
         }
-        mism = wave_or64(mism);
+        __syncthreads();
+        const uint64_t mism = sh_mism;
         const bool conv = !((mism >> lane) & 1ull);
         const bool done = active && (conv || iter >= a.max_iter);
         const uint64_t donemask = __ballot(done);
@@ -685,13 +707,15 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
             // ---- harvest ------------------------------------------------------
             bool fail = false, det = !conv;
             if (a.test != TEST_NONE) {
+                for (uint32_t i = tid; i < 128; i += NT) sh_flag[i >> 6][i & 63] = 0;
+                __syncthreads();
                 uint64_t rany = 0;
-                for (uint32_t w = 0; w < Wn; w++)
+                for (uint32_t w = wv; w < Wn; w += NW)
                     if (done) rany |= ew[(size_t)w * 64 + lane] ^ dw[(size_t)w * 64 + lane];
-                if (a.test == TEST_RESIDUAL) fail = rany != 0;
-                else {
+                if (rany) atomicOr(&sh_flag[0][lane], 1u);
+                if (a.test == TEST_LOGICAL) {
                     uint32_t lfail = 0;
-                    for (uint32_t r = 0; r < a.l_rows; r++) {
+                    for (uint32_t r = wv; r < a.l_rows; r += NW) {
                         uint32_t par = 0;
                         for (uint32_t k = a.l_ptr[r]; k < a.l_ptr[r + 1]; k++) {
                             uint32_t b = a.l_idx[k];
@@ -702,123 +726,200 @@ __global__ __launch_bounds__(64) void bp_kernel(DeviceGraph g, BpArgs a)
                         }
                         lfail |= par;
                     }
-                    fail = det || lfail;
+                    if (lfail) atomicOr(&sh_flag[1][lane], 1u);
                 }
+                __syncthreads();
+                if (a.test == TEST_RESIDUAL) fail = sh_flag[0][lane] != 0;
+                else fail = det || sh_flag[1][lane] != 0;
             }
             if (done) {
-                if (a.iters_out) a.iters_out[myi] = iter;
                 if (a.corr_out)
-                    for (uint32_t w = 0; w < Wn; w++) {
+                    for (uint32_t w = wv; w < Wn; w += NW) {
                         uint64_t x = dw[(size_t)w * 64 + lane];
                         if (a.xor_input) x ^= ew[(size_t)w * 64 + lane];
                         a.corr_out[myi * Wn + w] = x;
                     }
                 if (a.post_out)
-                    for (uint32_t b = 0; b < n; b++) {      // BpState::decode posterior, :100-106
+                    for (uint32_t b = wv; b < n; b += NW) {      // BpState::decode posterior, :100-106
                         double l = prior;
                         if (!fresh)
                             for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) l += chkm[(size_t)g.t_edge[k] * 64 + lane];
                         a.post_out[myi * n + b] = l;
                     }
-                if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
-                c_shots++; c_fail += fail; c_det += det; c_work += iter;
+                if (wv == 0) {
+                    if (a.iters_out) a.iters_out[myi] = iter;
+                    if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
+                    c_shots++; c_fail += fail; c_det += det; c_work += iter;
+                }
                 active = false;
             }
-            if (next < end) continue;   // refill before spending an iteration
+            __syncthreads();
+            if (!drained) continue;     // refill before spending an iteration
             if (!__ballot(active)) break;
         }
 
         // ---- one BP iteration on the active slots (update_once, :133-140) -----
-        // update_checks (:150-166)
-        for (uint32_t c = 0; c < m; c++) {
-            const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
-            const bool sbit = (ssl[c] >> lane) & 1ull;
-            if (dc <= REG_DEG) {
-                double t[REG_DEG];
+        // update_checks (:150-166): the waves take the checks round-robin
+        if constexpr (DC > 0) {
+            // software pipeline: the DC message rows of the wave's next check are in flight while the
+            // tanh / log1p chains of the current one run
+            double xn[DC];
+            if (wv < m) {
+#pragma unroll
+                for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)wv * DC + j) * 64 + lane];
+            }
+            for (uint32_t c = wv; c < m; c += NW) {
+                const size_t e0 = (size_t)c * DC;
+                const bool sbit = (ssl[c] >> lane) & 1ull;
+                double x[DC], t[DC];
+#pragma unroll
+                for (int j = 0; j < DC; j++) x[j] = xn[j];
+                if (c + NW < m) {
+#pragma unroll
+                    for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
+                }
+#pragma unroll
+                for (int j = 0; j < DC; j++) t[j] = tanh(x[j] / 2.0);
                 double prod = 1.0;
 #pragma unroll
-                for (uint32_t j = 0; j < REG_DEG; j++)
-                    if (j < dc) {
-                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        t[j] = tanh(x / 2.0);
-                        prod *= t[j];
-                    }
+                for (int j = 0; j < DC; j++) prod *= t[j];
 #pragma unroll
-                for (uint32_t j = 0; j < REG_DEG; j++)
-                    if (j < dc) {
-                        double v = 2.0 * ref_atanh(prod / t[j]);
+                for (int j = 0; j < DC; j++) {
+                    double v = 2.0 * ref_atanh(prod / t[j]);
+                    if (sbit) v *= -1.0;
+                    if (active) chkm[(e0 + j) * 64 + lane] = v;
+                }
+            }
+        } else {
+            for (uint32_t c = wv; c < m; c += NW) {
+                const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+                const bool sbit = (ssl[c] >> lane) & 1ull;
+                if (dc <= REG_DEG) {
+                    double t[REG_DEG];
+                    double prod = 1.0;
+#pragma unroll
+                    for (uint32_t j = 0; j < REG_DEG; j++)
+                        if (j < dc) {
+                            double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                            t[j] = tanh(x / 2.0);
+                            prod *= t[j];
+                        }
+#pragma unroll
+                    for (uint32_t j = 0; j < REG_DEG; j++)
+                        if (j < dc) {
+                            double v = 2.0 * ref_atanh(prod / t[j]);
+                            if (sbit) v *= -1.0;
+                            if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
+                        }
+                } else {
+                    double prod = 1.0;
+                    for (uint32_t j = 0; j < dc; j++) {
+                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                        prod *= tanh(x / 2.0);
+                    }
+                    for (uint32_t j = 0; j < dc; j++) {
+                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                        double v = 2.0 * ref_atanh(prod / tanh(x / 2.0));
                         if (sbit) v *= -1.0;
                         if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                     }
-            } else {
-                double prod = 1.0;
-                for (uint32_t j = 0; j < dc; j++) {
-                    double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                    prod *= tanh(x / 2.0);
-                }
-                for (uint32_t j = 0; j < dc; j++) {
-                    double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                    double v = 2.0 * ref_atanh(prod / tanh(x / 2.0));
-                    if (sbit) v *= -1.0;
-                    if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                 }
             }
         }
-        // update_bits (:168-180) + hard decision (:100-113)
-        uint64_t dacc = 0, slice = 0;
-        for (uint32_t b = 0; b < n; b++) {
-            const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
-            double sum = 0.0, post = prior;
-            if (dv <= REG_DEG) {
-                double v[REG_DEG];
-                uint32_t ed[REG_DEG];
+        __syncthreads();
+        // update_bits (:168-180) + hard decision (:100-113): the waves take 64-bit chunks round-robin
+        for (uint32_t chunk = wv; chunk < Wn; chunk += NW) {
+            uint64_t dacc = 0, slice = 0;
+            const uint32_t b0 = chunk * 64, b1 = b0 + 64 < n ? b0 + 64 : n;
+            if constexpr (DV > 0) {
+                // software pipeline over the bits of the chunk: next bit's DV rows in flight
+                double vn[DV];
+                uint32_t edn[DV];
 #pragma unroll
-                for (uint32_t k = 0; k < REG_DEG; k++)
-                    if (k < dv) {
-                        ed[k] = g.t_edge[k0 + k];
-                        v[k] = chkm[(size_t)ed[k] * 64 + lane];
+                for (int k = 0; k < DV; k++) {
+                    edn[k] = g.t_edge[b0 * (uint32_t)DV + k];
+                    vn[k] = chkm[(size_t)edn[k] * 64 + lane];
+                }
+                for (uint32_t b = b0; b < b1; b++) {
+                    double v[DV];
+                    uint32_t ed[DV];
+#pragma unroll
+                    for (int k = 0; k < DV; k++) { v[k] = vn[k]; ed[k] = edn[k]; }
+                    if (b + 1 < b1) {
+#pragma unroll
+                        for (int k = 0; k < DV; k++) {
+                            edn[k] = g.t_edge[(b + 1) * (uint32_t)DV + k];
+                            vn[k] = chkm[(size_t)edn[k] * 64 + lane];
+                        }
+                    }
+                    double sum = 0.0, post = prior;
+#pragma unroll
+                    for (int k = 0; k < DV; k++) {
                         sum += v[k];
                         post += v[k];
                     }
 #pragma unroll
-                for (uint32_t k = 0; k < REG_DEG; k++)
-                    if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+                    for (int k = 0; k < DV; k++)
+                        if (active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+                    const bool dec = post < 0.0;
+                    dacc |= (uint64_t)dec << (b & 63);
+                    uint64_t mask = __ballot(active && dec);
+                    if (lane == (b & 63)) slice = mask;
+                }
             } else {
-                for (uint32_t k = 0; k < dv; k++) {
-                    double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
-                    sum += v;
-                    post += v;
-                }
-                for (uint32_t k = 0; k < dv; k++) {
-                    size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
-                    if (active) bitsm[off] = sum - chkm[off] + prior;
+                for (uint32_t b = b0; b < b1; b++) {
+                    const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
+                    double sum = 0.0, post = prior;
+                    if (dv <= REG_DEG) {
+                        double v[REG_DEG];
+                        uint32_t ed[REG_DEG];
+#pragma unroll
+                        for (uint32_t k = 0; k < REG_DEG; k++)
+                            if (k < dv) {
+                                ed[k] = g.t_edge[k0 + k];
+                                v[k] = chkm[(size_t)ed[k] * 64 + lane];
+                                sum += v[k];
+                                post += v[k];
+                            }
+#pragma unroll
+                        for (uint32_t k = 0; k < REG_DEG; k++)
+                            if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+                    } else {
+                        for (uint32_t k = 0; k < dv; k++) {
+                            double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
+                            sum += v;
+                            post += v;
+                        }
+                        for (uint32_t k = 0; k < dv; k++) {
+                            size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
+                            if (active) bitsm[off] = sum - chkm[off] + prior;
+                        }
+                    }
+                    const bool dec = post < 0.0;
+                    dacc |= (uint64_t)dec << (b & 63);
+                    uint64_t mask = __ballot(active && dec);
+                    if (lane == (b & 63)) slice = mask;
                 }
             }
-            const bool dec = post < 0.0;
-            dacc |= (uint64_t)dec << (b & 63);
-            uint64_t mask = __ballot(active && dec);
-            if (lane == (b & 63)) slice = mask;
-            if ((b & 63) == 63 || b == n - 1) {
-                if (active) dw[(size_t)(b >> 6) * 64 + lane] = dacc;
-                uint32_t bb = (b & ~63u) + lane;
-                if (bb <= b) dsl[bb] = (dsl[bb] & ~actmask) | slice;
-                dacc = 0;
-                slice = 0;
-            }
+            if (active) dw[(size_t)chunk * 64 + lane] = dacc;
+            const uint32_t bb = b0 + lane;
+            if (bb < b1) dsl[bb] = (dsl[bb] & ~actmask) | slice;
         }
         if (active) { iter++; fresh = false; }
-        wave_sync();
+        __syncthreads();
     }
-    c_shots = wave_sum64(c_shots); c_fail = wave_sum64(c_fail); c_det = wave_sum64(c_det); c_work = wave_sum64(c_work);
-    if (lane == 0 && a.counters) {
-        if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
-        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
-        if (c_det) {
-            atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
-            atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_det);
+    if (wv == 0) {
+        c_shots = wave_sum64(c_shots); c_fail = wave_sum64(c_fail); c_det = wave_sum64(c_det); c_work = wave_sum64(c_work);
+        if (lane == 0 && a.counters) {
+            if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+            if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+            if (c_det) {
+                atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+                atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_det);
+            }
+            if (c_fail - c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
+            if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
         }
-        if (c_fail - c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
-        if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
     }
 }
 
@@ -936,10 +1037,15 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
     return hipGetLastError();
 }
 
-hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, hipStream_t st)
+hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uint32_t waves, int dc, int dv,
+                     hipStream_t st)
 {
     if (!a.n_shots || !groups) return hipSuccess;
-    hipLaunchKernelGGL(bp_kernel, dim3(groups), dim3(64), 0, st, g, a);
+    const dim3 grid(groups), block(64 * waves);
+    if (dc == 6 && dv == 3) hipLaunchKernelGGL((bp_kernel<6, 3>), grid, block, 0, st, g, a);
+    else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bp_kernel<4, 3>), grid, block, 0, st, g, a);
+    else if (dc == 7) hipLaunchKernelGGL((bp_kernel<7, 0>), grid, block, 0, st, g, a);
+    else hipLaunchKernelGGL((bp_kernel<0, 0>), grid, block, 0, st, g, a);
     return hipGetLastError();
 }
 

@@ -44,7 +44,8 @@ struct BpArgs {
     uint32_t max_iter;
     uint32_t fail_bit;          // OR-ed into failed_out on failure
     double prior;               // ln((1-p)/p), belief_propagation.rs:38
-    uint64_t seed, first_shot, n_shots, quota;
+    uint64_t seed, first_shot, n_shots;
+    unsigned long long *queue;  // device counter, zero at launch: shots handed out so far
     const uint64_t *words_in;   // [n_shots][Wn]
     const uint64_t *synd_in;    // [n_shots][Wm]
     uint64_t *corr_out;         // [n_shots][Wn] or null
@@ -88,7 +89,10 @@ hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_
                            hipStream_t st);
 hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st);
 hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st);
-hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, hipStream_t st);
+// dc / dv: the common check / bit degree of a regular code, 0 when degrees vary
+// groups = workgroups (64 shot slots each), waves = wavefronts per workgroup sharing a group
+hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uint32_t waves, int dc, int dv,
+                     hipStream_t st);
 // counters[FAILURES] += #{flags != 0}, [XFAIL] += #{flags & 1}, [ZFAIL] += #{flags & 2}
 hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
 

@@ -1,0 +1,17 @@
+"""One BP Monte-Carlo launch (for rocprofv3 passes).  usage: bp_one.py [config] [shots] [p]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ldpc_amd
+from ldpc_amd import BpDecoder, LinearCode
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+shots = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
+p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+shape = {"c1": (1200, 900, 3, 4), "c2": (10000, 5000, 3, 6), "c5": (1000000, 500000, 3, 6)}[cfg]
+code = LinearCode.random_regular_code(*shape, seed=1)
+dec = BpDecoder(code, p, 100)
+dec.mc_run(p, 1, 0, 4096 if cfg != "c5" else 64)
+c = dec.mc_run(p, 2024, 0, shots)
+ms = ldpc_amd.last_kernel_ms()
+E = code.num_edges()
+print("cfg", cfg, "kernel_ms", ms, "shots", shots, "iters", int(c[4]), "fail", int(c[1]),
+      "algorithmic_GBs", int(c[4]) * 32 * E / (ms * 1e-3) / 1e9)
