@@ -33,7 +33,7 @@ CODE_SEED, NOISE_SEED = 1, 2024
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(code, budget_s=12.0):
+def cpu_baseline(code, budget_s=15.0):
     """The oracle's restatement of FlipDecoder::decode as written in the reference
     (flip.rs:21-43: rescan from bit 0 and a full H*e_bit per flip), timed on this
     host on a bounded sample of the same workload."""
@@ -42,10 +42,9 @@ def cpu_baseline(code, budget_s=12.0):
     oc = orc.Code(code.len(), ptr=ptr.astype(np.int64), idx=idx.astype(np.uint32))
     threads = max(1, min(16, orc.max_threads(), os.cpu_count() or 1))
     t0 = time.perf_counter()
-    oc.mc_flip(P, NOISE_SEED, 0, threads, reference_style=True, nthreads=threads)
-    per_round = max(time.perf_counter() - t0, 1e-3)
-    rounds = int(max(1, min(64, budget_s / per_round)))
-    shots = rounds * threads
+    oc.mc_flip(P, NOISE_SEED, 0, 2 * threads, reference_style=True, nthreads=threads)
+    per_shot = max(time.perf_counter() - t0, 1e-3) / (2 * threads)          # thread-seconds per shot / threads
+    shots = int(max(threads, min(20000, budget_s / per_shot)))
     t0 = time.perf_counter()
     cnt = oc.mc_flip(P, NOISE_SEED, 0, shots, reference_style=True, nthreads=threads)
     dt = time.perf_counter() - t0
@@ -63,6 +62,35 @@ def cpu_baseline(code, budget_s=12.0):
     }, cnt
 
 
+def measured_traffic(shots_per_launch):
+    """HBM-side bytes per launch from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE), kept in profiles/r01_flip_pmc.json;
+    scaled to this run's shots per launch.  None when no profile is on record."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_flip_pmc.json")) as f:
+            prof = json.load(f)
+        return prof["traffic_bytes_per_shot"] * shots_per_launch
+    except Exception:
+        return None
+
+
+def bp_line(code, shots=1 << 18):
+    """Secondary measurement: the f64 BP kernel on the same code and channel (Monte-Carlo mode,
+    max 100 iterations).  Algorithmic bytes = 32*E per shot-iteration."""
+    import ldpc_amd
+    from ldpc_amd import BpDecoder
+    dec = BpDecoder(code, P, 100)
+    dec.mc_run(P, NOISE_SEED, 1 << 40, 8192)
+    cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
+    ms = ldpc_amd.last_kernel_ms()
+    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
+    return {"workload": "same code and channel, BpDecoder f64, max 100 iterations, %d shots" % shots,
+            "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<6,3>", "kernel_ms": ms,
+            "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shots-per-step", type=int, default=1 << 20, help="shots per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bp", action="store_true", help="skip the secondary BP measurement")
     args = ap.parse_args()
 
     import torch
@@ -148,8 +177,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "flip_kernel", "kernel_ms": avg_kernel_s * 1e3,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
+                "kernel": "flip2_kernel", "kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
             },
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
@@ -157,6 +186,8 @@ def main():
         if not args.no_cpu_baseline:
             cb, _ = cpu_baseline(code)
             line["cpu_baseline"] = cb
+        if not args.no_bp and world == 1:
+            line["bp"] = bp_line(code)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -383,7 +383,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     size_t per_group = bp_workspace_bytes_per_group(g);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.6), (size_t)96 << 30);
+    size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.75), (size_t)200 << 30);
     uint32_t waves = 1;
     while (waves < 16 && (size_t)g.E > (size_t)4096 * waves) waves *= 2;
     if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(16, std::atoi(e)));   // A/B aid
