@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -377,22 +378,30 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         return LDPC_OK;
     }
     // shot groups of 64 slots, one workgroup each.  Waves per group grow with the code (an iteration of
-    // a 64-shot group costs ~E row updates: split over up to 16 waves so that a straggler shot does not
-    // hold a multi-millisecond iteration on one wave); groups are bounded by memory and by what fills
-    // the chip (~16 waves per CU).
+    // a 64-shot group costs ~E row updates: split over up to 8 waves so that a straggler shot does not
+    // hold a long iteration on one wave); groups are bounded by memory and by what is resident at once.
     size_t per_group = bp_workspace_bytes_per_group(g);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.75), (size_t)200 << 30);
-    uint32_t waves = 1;
-    while (waves < 16 && (size_t)g.E > (size_t)4096 * waves) waves *= 2;
-    if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(16, std::atoi(e)));   // A/B aid
-    uint64_t max_groups = std::min<uint64_t>(4096 / waves, budget / std::max<size_t>(per_group, 1));
+    // measured (scripts/bp_probe.py): C2 (E = 30000) and C1 (E = 3600) run fastest with 8 waves per
+    // group, the 625-qubit HGP code (E = 2100) with 4: shorter iterations, shorter straggler tail
+    const uint32_t waves_default = g.E <= 256 ? 1u : g.E <= 1024 ? 2u : g.E <= 3000 ? 4u : 8u;
+    uint32_t waves = waves_default;
+    if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(8, std::atoi(e)));   // A/B aid
+    // only as many groups as are resident at once: a queued workgroup would find the shot queue drained
+    uint64_t over = 1;
+    if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) over = (uint64_t)std::max(1, std::atoi(e));   // A/B aid
+    uint64_t max_groups = std::min<uint64_t>(over * bp_resident_groups(waves, dec->reg_dc, dec->reg_dv),
+                                             budget / std::max<size_t>(per_group, 1));
     if (max_groups == 0)
         return fail(LDPC_ERR_CAPACITY, "bp decoder: one shot group needs " + std::to_string(per_group) +
                                            " bytes of message storage, more than the device can give");
     uint64_t groups = std::min<uint64_t>(max_groups, (r.n_shots + 63) / 64);
     groups = std::max<uint64_t>(groups, 1);
+    if (std::getenv("LDPC_HIP_DEBUG"))
+        std::fprintf(stderr, "[ldpc_hip] bp: E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", g.E, waves,
+                     (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
     HIP_TRY(dec->workspace.reserve(per_group * groups));
 
     BpArgs a{};
@@ -1103,5 +1112,15 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
 }
 
 void ldpc_css_bp_destroy(ldpc_css_bp_decoder *dec) { delete dec; }
+
+// Not part of the drop-in ABI (absent from include/ldpc_hip.h): lets the tests measure the
+// accuracy of the BP kernel's tanh(x/2) / log1p routines (csrc/bp_math.hpp) on device arrays.
+int ldpc_internal_bp_math(int kind, size_t n, const double *d_in, double *d_out)
+{
+    if (n && (!d_in || !d_out)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    HIP_TRY(launch_bp_math_probe(kind, n, d_in, d_out, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return LDPC_OK;
+}
 
 }  // extern "C"

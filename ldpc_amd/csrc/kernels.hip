@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "bp_math.hpp"
 #include "kernels.hpp"
 
 namespace ldpc {
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(256) void syndrome_kernel(DeviceGraph g, uint64_t n
             if (lane == 0) synd[i * Wm + (base >> 6)] = mask;
         }
     }
+}
+
+// test probe for bp_math.hpp: kind 0 = bp_tanh_half, 1 = bp_log1p
+__global__ __launch_bounds__(256) void bp_math_probe_kernel(int kind, uint64_t n, const double *in, double *out)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
+        out[t] = kind == 0 ? bp_tanh_half(in[t]) : kind == 1 ? bp_log1p(in[t]) : kind == 2 ? tanh(in[t] / 2.0) : log1p(in[t]);
 }
 
 __global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *flags, uint64_t n, unsigned long long *counters)
@@ -584,12 +592,12 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 
 // f64::atanh of the reference's toolchain: 0.5 * ln_1p(2x / (1 - x))
-__device__ inline double ref_atanh(double x) { return 0.5 * log1p((2.0 * x) / (1.0 - x)); }
+__device__ inline double ref_atanh(double x) { return 0.5 * bp_log1p((2.0 * x) / (1.0 - x)); }
 
 // DC / DV > 0: every check has exactly DC bits / every bit exactly DV checks (regular code):
 // rows start at c*DC, loops are fully unrolled and the DC (DV) independent tanh / log1p chains of
 // a row interleave.  0 = any degrees (row pointers, runtime trip counts).
-template <int DC, int DV> __global__ __launch_bounds__(1024) void bp_kernel(DeviceGraph g, BpArgs a)
+template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(DeviceGraph g, BpArgs a)
 {
     __shared__ uint32_t q[65];
     __shared__ unsigned long long sh_queue, sh_mism;
@@ -779,7 +787,7 @@ template <int DC, int DV> __global__ __launch_bounds__(1024) void bp_kernel(Devi
                     for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
                 }
 #pragma unroll
-                for (int j = 0; j < DC; j++) t[j] = tanh(x[j] / 2.0);
+                for (int j = 0; j < DC; j++) t[j] = bp_tanh_half(x[j]);
                 double prod = 1.0;
 #pragma unroll
                 for (int j = 0; j < DC; j++) prod *= t[j];
@@ -801,7 +809,7 @@ template <int DC, int DV> __global__ __launch_bounds__(1024) void bp_kernel(Devi
                     for (uint32_t j = 0; j < REG_DEG; j++)
                         if (j < dc) {
                             double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                            t[j] = tanh(x / 2.0);
+                            t[j] = bp_tanh_half(x);
                             prod *= t[j];
                         }
 #pragma unroll
@@ -815,11 +823,11 @@ template <int DC, int DV> __global__ __launch_bounds__(1024) void bp_kernel(Devi
                     double prod = 1.0;
                     for (uint32_t j = 0; j < dc; j++) {
                         double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        prod *= tanh(x / 2.0);
+                        prod *= bp_tanh_half(x);
                     }
                     for (uint32_t j = 0; j < dc; j++) {
                         double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        double v = 2.0 * ref_atanh(prod / tanh(x / 2.0));
+                        double v = 2.0 * ref_atanh(prod / bp_tanh_half(x));
                         if (sbit) v *= -1.0;
                         if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                     }
@@ -1037,15 +1045,39 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
     return hipGetLastError();
 }
 
+typedef void (*bp_kernel_fn)(DeviceGraph, BpArgs);
+
+static bp_kernel_fn bp_kernel_for(int dc, int dv)
+{
+    if (dc == 6 && dv == 3) return bp_kernel<6, 3>;
+    if (dc == 4 && dv == 3) return bp_kernel<4, 3>;
+    if (dc == 7) return bp_kernel<7, 0>;
+    return bp_kernel<0, 0>;
+}
+
+// workgroups of `waves` wavefronts that are resident at once on the whole device
+uint32_t bp_resident_groups(uint32_t waves, int dc, int dv)
+{
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bp_kernel_for(dc, dv), (int)(64 * waves), 0) != hipSuccess ||
+        per_cu < 1)
+        per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (uint32_t)per_cu * (uint32_t)(cus > 0 ? cus : 256);
+}
+
 hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uint32_t waves, int dc, int dv,
                      hipStream_t st)
 {
     if (!a.n_shots || !groups) return hipSuccess;
-    const dim3 grid(groups), block(64 * waves);
-    if (dc == 6 && dv == 3) hipLaunchKernelGGL((bp_kernel<6, 3>), grid, block, 0, st, g, a);
-    else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bp_kernel<4, 3>), grid, block, 0, st, g, a);
-    else if (dc == 7) hipLaunchKernelGGL((bp_kernel<7, 0>), grid, block, 0, st, g, a);
-    else hipLaunchKernelGGL((bp_kernel<0, 0>), grid, block, 0, st, g, a);
+    hipLaunchKernelGGL(bp_kernel_for(dc, dv), dim3(groups), dim3(64 * waves), 0, st, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(bp_math_probe_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, kind, n, d_in, d_out);
     return hipGetLastError();
 }
 

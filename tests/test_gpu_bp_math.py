@@ -1,0 +1,80 @@
+"""Accuracy and edge behaviour of the BP kernel's own tanh(x/2) and log1p (csrc/bp_math.hpp),
+measured on the MI355X against mpmath at 60 digits.  Bar: tanh(x/2) <= 0.6 ulp, log1p <= 0.85 ulp
+(glibc's tanh reaches 1.15 ulp, OCML's log1p 0.62: scripts/math_ulps.py) and exact
+IEEE results at the edges the un-clamped BP arithmetic reaches."""
+import ctypes as C
+import math
+
+import mpmath
+import numpy as np
+import pytest
+
+import ldpc_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(kind, x):
+    import torch
+    L = ldpc_amd.lib()
+    fn = L.ldpc_internal_bp_math
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    d_in = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to("cuda")
+    d_out = torch.empty_like(d_in)
+    assert fn(kind, d_in.numel(), d_in.data_ptr(), d_out.data_ptr()) == 0
+    return d_out.cpu().numpy()
+
+
+def _ulp_err(got, ref_fn, xs):
+    mpmath.mp.dps = 60
+    worst = 0.0
+    for g, x in zip(got, xs):
+        r = ref_fn(mpmath.mpf(float(x)))
+        rf = float(r)
+        if rf == 0.0:
+            assert g == 0.0
+            continue
+        ulp = math.ulp(rf)
+        worst = max(worst, abs(float((mpmath.mpf(float(g)) - r) / ulp)))
+    return worst
+
+
+def test_tanh_half_accuracy():
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-80, 80, 3000), rng.uniform(-1, 1, 3000), rng.uniform(-0.51, -0.49, 200),
+                         rng.uniform(0.49, 0.51, 200), 10.0 ** rng.uniform(-300, 0, 500), rng.uniform(36, 39, 300),
+                         np.array([3.8918202981106265, 7.783640596221253, 0.5, -0.5, 1e-320, 745.0, -745.0])])
+    got = _run(0, xs)
+    assert _ulp_err(got, lambda v: mpmath.tanh(v / 2), xs) <= 0.6
+    assert (np.abs(got) <= 1.0).all()
+
+
+def test_tanh_half_edges():
+    xs = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 100.0, -100.0, 1e300, -1e300])
+    got = _run(0, xs)
+    assert got[0] == 0.0 and not np.signbit(got[0])
+    assert got[1] == 0.0 and np.signbit(got[1])
+    assert got[2] == 1.0 and got[3] == -1.0 and np.isnan(got[4])
+    assert got[5] == 1.0 and got[6] == -1.0 and got[7] == 1.0 and got[8] == -1.0     # saturates exactly, as libm does
+
+
+def test_log1p_accuracy():
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([rng.uniform(-0.999999, 5, 4000), 10.0 ** rng.uniform(-300, 300, 2000),
+                         -(10.0 ** rng.uniform(-300, -1e-9, 1000)), rng.uniform(-0.30, -0.28, 300),
+                         rng.uniform(0.40, 0.43, 300), -1 + 10.0 ** rng.uniform(-16, -1, 500),
+                         np.array([0.41421356237309515, -0.2928932188134524, 2.0 ** 53, 2.0 ** 54, 1e-320])])
+    got = _run(1, xs)
+    assert _ulp_err(got, mpmath.log1p, xs) <= 0.85
+
+
+def test_log1p_edges():
+    xs = np.array([0.0, -0.0, -1.0, -1.0000000000000002, -2.0, -np.inf, np.inf, np.nan, 1.7976931348623157e308])
+    got = _run(1, xs)
+    assert got[0] == 0.0 and not np.signbit(got[0])
+    assert got[1] == 0.0 and np.signbit(got[1])
+    assert got[2] == -np.inf
+    assert np.isnan(got[3]) and np.isnan(got[4]) and np.isnan(got[5])
+    assert got[6] == np.inf and np.isnan(got[7])
+    assert abs(got[8] - 709.782712893384) < 1e-9
