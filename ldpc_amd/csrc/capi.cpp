@@ -184,7 +184,7 @@ struct ldpc_css_code {
 struct ldpc_flip_decoder {
     ldpc_code code;
     std::mutex mu;
-    DeviceBuffer counters, nb, o_scratch;
+    DeviceBuffer counters, nb, o_scratch, flip_log;
     NbTable nbt{};
     int path = 0;   // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel
 };
@@ -325,10 +325,13 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         }
     }
     if (dec->path == 2) {
-        if (!a.words_out) {
+        if (!a.errors_out) {
             HIP_TRY(dec->o_scratch.reserve((size_t)flip2_max_blocks(g) * 8 * std::max<size_t>(words_for(g.n), 1) * 8));
             a.o_scratch = dec->o_scratch.as<uint64_t>();
         }
+        a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
+        HIP_TRY(dec->flip_log.reserve((size_t)flip2_max_blocks(g) * 8 * a.flip_log_cap * 4));
+        a.flip_log = dec->flip_log.as<uint32_t>();
         KernelTimer timer;
         HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
         timer.stop_and_store();

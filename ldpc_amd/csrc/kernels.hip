@@ -373,13 +373,14 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
 
     for (uint64_t base = (uint64_t)blockIdx.x * SPW; base < a.n_shots; base += (uint64_t)gridDim.x * SPW) {
         const uint32_t nvalid = a.n_shots - base < SPW ? (uint32_t)(a.n_shots - base) : SPW;
-        // output word of shot j: the caller's buffer, or this block's scratch slice
-        auto out_words = [&](uint32_t j) -> uint64_t * {
-            return a.words_out ? a.words_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * SPW + j) * Wn;
+        // the sampled / given word of shot j is parked in HBM during the flip loop (the caller's record
+        // buffer, or this block's scratch slice); the flips are logged and applied to it at the end
+        auto err_words = [&](uint32_t j) -> uint64_t * {
+            return a.errors_out ? a.errors_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * SPW + j) * Wn;
         };
         // ------------------------------------------------------------------ set-up, wave-wide, shot by shot
         for (uint32_t j = 0; j < nvalid; j++) {
-            uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = out_words(j);
+            uint64_t *S = state + (size_t)j * per_shot, *F = S + Wm, *O = err_words(j);
             uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *FS32 = (uint32_t *)(F + Wn);
             const uint64_t i = base + j, shot = a.first_shot + i;
             for (uint32_t w = lane; w < Wm; w += 64) S[w] = 0;
@@ -396,7 +397,6 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
                     if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
                 }
                 O[w] = x;
-                if (a.errors_out) a.errors_out[i * Wn + w] = x;
                 const uint32_t cc = (uint32_t)__builtin_popcountll(x);
                 if (cc) {
                     uint32_t off = atomicAdd(cnt_lds, cc);
@@ -474,7 +474,10 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
         {
             uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm, *FS = F + Wn;
             uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *FS32 = (uint32_t *)FS;
-            uint32_t *O32 = (uint32_t *)out_words(grp < nvalid ? grp : 0);
+            // flip log of this group's shot: G flips are gathered in registers (lane t keeps flip t mod G),
+            // then written as one coalesced row; at most m flips per shot (each lowers the syndrome weight)
+            uint32_t *flog = a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;
+            uint32_t mylog = 0;
             bool active = grp < nvalid;
             uint32_t curS = 0, nfl = 0;   // invariant: no flippable bit in F words below 64*curS
             const uint32_t max_flips = a.max_flips;
@@ -534,11 +537,12 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
                     }
                     if (big && fl) minset = rec.bit < minset ? rec.bit : minset;
                 }
-                // output ^= e_b (flip.rs:30): an L2 atomic, issued after this iteration's row has been
-                // consumed so that it retires under the next iteration's LDS work and row load
-                if (found && gl == 0)
-                    __hip_atomic_fetch_xor(&O32[b >> 5], 1u << (b & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (found) nfl++;
+                // output ^= e_b (flip.rs:30) is deferred: log the flip
+                if (found) {
+                    if ((nfl & (G - 1)) == gl) mylog = b;
+                    nfl++;
+                    if ((nfl & (G - 1)) == 0) flog[nfl - G + gl] = mylog;
+                }
                 if (big) {   // more summary words than lanes: keep the scan cursor at the lowest possible word
                     minset = group_min_u32<G>(minset);
                     if (found) {
@@ -550,18 +554,32 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
                 if (DIAG && active) c_iters++;                  // profiling aid: loop iterations incl. empty ones
                 if (DIAG && nfl >= max_flips) active = false;   // profiling aid only
             }
-            wave_sync();   // the output-word atomics have landed
+            if (gl < (nfl & (G - 1))) flog[(nfl & ~(uint32_t)(G - 1)) + gl] = mylog;   // last, partial row
+            wave_sync();   // log rows are in memory
             // ---------------------------------------------------------------- failure test + outputs
             for (uint32_t j = 0; j < nvalid; j++) {
-                const uint64_t *Sj = state + (size_t)j * per_shot;
-                uint64_t *Oj = out_words(j);
+                uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Wm;   // F is dead: rebuild the word there
+                uint32_t *O32 = (uint32_t *)Oj;
+                const uint64_t *Ej = err_words(j);
+                const uint32_t *lj = a.flip_log + ((size_t)blockIdx.x * SPW + j) * a.flip_log_cap;
                 const uint64_t i = base + j;
+                const uint32_t nf = __shfl(nfl, j * G, 64);
+                // device-scope loads: both were written by this wave, possibly through another lane
+                for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&Ej[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wave_order();
+                for (uint32_t t = lane; t < nf; t += 64) {
+                    const uint32_t b = __hip_atomic_load(&lj[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicXor(&O32[b >> 5], 1u << (b & 31));                // flip.rs:30
+                }
+                wave_order();
                 uint64_t anyo = 0, anys = 0;
-                for (uint32_t w = lane; w < Wn; w += 64)   // device-scope loads: the flips were applied by L2 atomics
-                    anyo |= __hip_atomic_load(&Oj[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t w = lane; w < Wn; w += 64) {
+                    const uint64_t x = Oj[w];
+                    anyo |= x;
+                    if (a.words_out) a.words_out[i * Wn + w] = x;
+                }
                 for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
                 const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
-                const uint32_t nf = __shfl(nfl, j * G, 64);
                 if (a.flips_out && lane == 0) a.flips_out[i] = nf;
                 c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nf;
             }

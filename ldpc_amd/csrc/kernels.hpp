@@ -33,7 +33,9 @@ struct FlipArgs {
     uint32_t *flips_out;        // [n_shots]      or null
     unsigned long long *counters;   // [LDPC_COUNTERS] device, accumulated
     uint32_t max_flips;         // diagnostics: stop a shot after this many flips (default: unlimited)
-    uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][shots per wave][Wn] output words when words_out is null
+    uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][shots per wave][Wn] parked input words when errors_out is null
+    uint32_t *flip_log;         // fast kernel: [flip2_max_blocks][shots per wave][flip_log_cap] flipped bits
+    uint32_t flip_log_cap;      // >= m rounded up to 16, + 16
     GapTable gap;
 };
 
