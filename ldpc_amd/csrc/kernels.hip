@@ -340,18 +340,19 @@ __device__ inline uint32_t half_row_min_u32(uint32_t v)
 __device__ inline uint32_t row_min_u32(uint32_t v)
 {
     uint32_t o;
-    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
     v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);   // row_ror:4
     v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, true);   // row_ror:2
     v = o < v ? o : v;
-    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);   // row_ror:1
     v = o < v ? o : v;
     return v;
 }
 
-template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
+// ONE: K == G, every row is exactly one round of the group (kshift becomes a constant, the round loop unrolls away)
+template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
     constexpr uint32_t SPW = 64 / G;                 // shots per wave
@@ -364,7 +365,7 @@ template <int DVP, int G, bool REG, bool DIAG> __global__ __launch_bounds__(64) 
     uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 2);
     uint64_t *state = lds + FLIP2_HDR;
     const NbRec<DVP> *nb = (const NbRec<DVP> *)nbt.rec;
-    const uint32_t kshift = nbt.kshift, K = 1u << kshift;
+    const uint32_t kshift = ONE ? (G == 16 ? 4u : 3u) : nbt.kshift, K = 1u << kshift;
 
     for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
     wave_sync();
@@ -1037,12 +1038,15 @@ template <int DVP, int G>
 static void launch_flip2_t(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, uint32_t grid, size_t lds, hipStream_t st)
 {
     const bool diag = a.max_flips != 0xFFFFFFFFu;
+    const bool one = !diag && (1u << nb.kshift) == (uint32_t)G;
     if (nb.regular) {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else if (one) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
     } else {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else if (one) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        else hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
     }
 }
 
