@@ -6,25 +6,56 @@
 // ulp-level accuracy and IEEE behaviour at the edges (+-0, +-1, +-inf, NaN,
 // arguments < -1), because the kernel has no clamps.  OCML's tanh and log1p cost
 // 166 and 135 VALU instructions per call (double-double internals) and made the
-// kernel issue-bound; these cost about 85 and 65 and round correctly about as often as the libms do
+// kernel issue-bound; these cost about 60 and 45 and round correctly about as often as the libms do
 // (tests/test_gpu_bp_math.py, scripts/math_ulps.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ldpc {
 
-// tanh(x/2).
-// |x| < 0.5: odd Taylor series of tanh in h = x/2 (|h| < 0.25, 12 terms, truncation < 1e-19).
-// |x| >= 0.5: (1 - E) / (1 + E), E = e^-|x|.  A plain double E is not enough (its half-ulp error is
+// a / b without the scaling and fix-up steps of the IEEE expansion (13-14 instructions): hardware
+// reciprocal (about 23 bits), one Newton step, quotient, one residual correction.  The result is the
+// correctly rounded quotient except in a vanishing fraction of near-tie cases (tests/test_gpu_bp_math.py)
+// PROVIDED b is finite, non-zero and neither it, 1/b, a/b nor the residual leave the normal range;
+// every call site below states why that holds or guards what does not.  A zero dividend gives +0 whatever
+// its sign (the residual step adds +0): in BP the sign of a zero message reaches no other value or decision.
+__device__ inline double bp_div_core(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// true when |v| < 2^-511 (zero and denormals included) or v is NaN / infinite
+__device__ inline bool bp_exponent_out_of_band(double v)
+{
+    return (uint32_t)((__double2hiint(v) & 0x7ff00000) - 0x20000000) >= 0x5ff00000u - 0x20000000u;
+}
+
+// prod / t of update_checks (belief_propagation.rs:158): |prod| <= |t| <= 1 (prod has t as a factor).
+// Fast path when t is in the normal band; any lane outside it (t == 0 gives the reference's 0/0 = NaN,
+// NaN inputs, denormal t) sends the wave through the IEEE division.
+__device__ inline double bp_div_prod(double prod, double t)
+{
+    double q = bp_div_core(prod, t);
+    if (__builtin_expect(__ballot(bp_exponent_out_of_band(t)) != 0, 0)) q = prod / t;
+    return q;
+}
+
+// tanh(x/2) = (1 - E) / (1 + E), E = e^-|x|.  A plain double E is not enough (its half-ulp error is
 // amplified up to 4x near |x| = 0.5, and 1 - E, 1 + E and the quotient each round once more: about half
 // of the results came out mis-rounded, which makes non-converging BP runs drift away from the CPU's
 // faster than libm-to-libm differences do).  So E is carried as an unevaluated sum Eh + El (Cody-Waite
 // reduction |x| = k ln2 - r, e^r = 1 + r + r^2 Q(r) with the rounding errors of the last additions kept),
-// numerator and denominator likewise, and the quotient gets one correction step.
+// numerator and denominator likewise, and the quotient gets one correction step.  For k = 0 the same
+// formulas give 1 - E = -(expm1 part) without cancellation, so one path serves every |x| >= 2^-8;
+// below that the odd Taylor series h - h^3/3 + 2h^5/15 (h = x/2, next term < 2^-58 relative) is used.
+// Measured: <= 0.55 ulp for |x| >= 0.5, <= 0.64 ulp below (the uncompensated rounding of r^2 Q(r) shows
+// when r is near ln2/2), 96-100 % correctly rounded; glibc's tanh: <= 1.15 ulp, about 80 %.
 __device__ inline double bp_tanh_half(double x)
 {
     const double a = fmin(fabs(x), 64.0);   // tanh(32) is 1.0 in f64 already; keeps 2^-k normal
-    // --- big path ---
     const double kd = rint(a * 1.4426950408889634074);
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double rh = kd * ln2_hi - a;            // exact (Cody-Waite, Sterbenz)
@@ -52,52 +83,44 @@ __device__ inline double bp_tanh_half(double x)
     const double eh = ldexp(sh, k), el = ldexp(sl, k);      // E = e^-a
     const double nh = 1.0 - eh, nl = ((1.0 - nh) - eh) - el;
     const double dh = 1.0 + eh, dl = ((1.0 - dh) + eh) + el;
-    const double q0 = nh / dh;
+    // (nh + nl) / (dh + dl): dh in [1, 2], 0 <= nh <= 1, no special operands
+    double rd = __builtin_amdgcn_rcp(dh);
+    rd = fma(fma(-dh, rd, 1.0), rd, rd);
+    const double q0 = nh * rd;
     const double rem = fma(-q0, dh, nh) + (nl - q0 * dl);
-    const double big = q0 + rem * __builtin_amdgcn_rcp(dh);
-    // --- small path ---
-    const double h = 0.5 * x, z = h * h;
-    double p = -0x1.497d8eea25259p-15;
-    p = fma(p, z, 0x1.967e18afcafadp-14);
-    p = fma(p, z, -0x1.f57d7734d1664p-13);
-    p = fma(p, z, 0x1.3558248036744p-11);
-    p = fma(p, z, -0x1.7da36452b75e3p-10);
-    p = fma(p, z, 0x1.d6d3d0e157de0p-9);
-    p = fma(p, z, -0x1.226e355e6c23dp-7);
-    p = fma(p, z, 0x1.664f4882c10fap-6);
-    p = fma(p, z, -0x1.ba1ba1ba1ba1cp-5);
-    p = fma(p, z, 0x1.1111111111111p-3);
-    p = fma(p, z, -0x1.5555555555555p-2);
-    const double small = fma(h * z, p, h);   // h + h^3 * P(h^2)
+    const double big = fma(rem, rd, q0);
+    const double h = 0.5 * a, z = h * h;
+    const double tiny = fma(h * z, fma(z, 2.0 / 15.0, -1.0 / 3.0), h);
     // tanh is odd: take the magnitude and put x's sign back (keeps -0)
-    const double t = copysign(a < 0.5 ? small : big, x);
+    const double t = copysign(a < 0.00390625 ? tiny : big, x);
     return x != x ? x : t;
 }
 
 // log1p(x), argument reduction and kernel polynomial of the classic fdlibm scheme
-// (1+x = 2^k (1+f), sqrt(1/2) < 1+f < sqrt(2); log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)), s = f/(2+f)),
-// written branch-free for a 64-lane wave.
-__device__ inline double bp_log1p(double x)
+// (1+x = 2^k (1+f), sqrt(1/2) < 1+f < sqrt(2); log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)), s = f/(2+f);
+// the rounding error of 1+x enters as the correction c), written branch-free for a 64-lane wave;
+// zeros, infinities, NaN and x <= -1 are patched in a block a wave enters only if one of its lanes
+// holds such an argument.
+__device__ inline double bp_log1p_main(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                  Lp7 = 1.479819860511658591e-01;
-    // -0.2929 < x < 0.4142: k = 0 and f = x exactly
-    const bool direct = x > -0.2928932188134524 && x < 0.41421356237309515;
     const double u = 1.0 + x;
     int hu = __double2hiint(u);
     int k = (hu >> 20) - 1023;
-    // rounding error of 1 + x, relative to u (a few digits suffice: |c| <= ulp(u))
+    // rounding error of 1 + x, relative to u (a few digits suffice when |c| <= ulp(u) is small against the result)
     double c = (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);
     hu &= 0x000fffff;
     const bool low = hu < 0x6a09e;                       // mantissa below sqrt(2)
     k += low ? 0 : 1;
     const double um = __hiloint2double(hu | (low ? 0x3ff00000 : 0x3fe00000), __double2loint(u));
     double f = um - 1.0;
-    if (direct) { k = 0; f = x; c = 0.0; }
+    // |x| < 2^-20: 1 + x keeps too few bits of x for c (known to 23 bits only) to make up; f = x exactly
+    if (fabs(x) < 0x1p-20) { f = x; c = 0.0; }
     const double hfsq = 0.5 * f * f;
-    const double s = f / (2.0 + f);
+    const double s = bp_div_core(f, 2.0 + f);            // 2 + f in [1.70, 2.42], |f| < 0.42 (or 0)
     const double z = s * s;
     double r = Lp7;
     r = fma(r, z, Lp6);
@@ -108,8 +131,14 @@ __device__ inline double bp_log1p(double x)
     r = fma(r, z, Lp1);
     r = r * z;
     const double dk = (double)k;
-    double res = dk * ln2_hi - ((hfsq - (s * (hfsq + r) + (dk * ln2_lo + c))) - f);
-    // edges: log1p(-1) = -inf, log1p(x < -1) = NaN, log1p(+inf) = +inf, NaN stays NaN
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + (dk * ln2_lo + c))) - f);
+}
+
+// arguments bp_log1p_main does not serve: NaN, -inf, +-0, +inf (class mask 0x267) and x <= -1
+__device__ inline bool bp_log1p_is_special(double x) { return __builtin_amdgcn_class(x, 0x267) || x <= -1.0; }
+
+__device__ inline double bp_log1p_fix(double x, double res)
+{
     if (x == 0.0) res = x;   // keeps -0
     if (x == -1.0) res = -__builtin_huge_val();
     if (x < -1.0) res = __builtin_nan("");
@@ -117,5 +146,25 @@ __device__ inline double bp_log1p(double x)
     if (x != x) res = x;
     return res;
 }
+
+__device__ inline double bp_log1p(double x)
+{
+    double res = bp_log1p_main(x);
+    if (__builtin_expect(__ballot(bp_log1p_is_special(x)) != 0, 0)) res = bp_log1p_fix(x, res);
+    return res;
+}
+
+// f64::atanh of the reference's toolchain, 0.5 * ln_1p(2x / (1 - x)) (belief_propagation.rs:159), for
+// |x| <= 1 or NaN (x is a product of tanh values divided by one of its factors): 1 - x is 0 (x == 1:
+// the quotient is 2/0 = +inf), or lies in [2^-53, 2], where the fast division applies.
+// bp_ref_atanh = 0.5 * bp_log1p(bp_atanh_arg(x))
+__device__ inline double bp_atanh_arg(double x)
+{
+    const double d = 1.0 - x;
+    const double q = bp_div_core(2.0 * x, d);
+    return d == 0.0 ? __builtin_huge_val() : q;
+}
+
+__device__ inline double bp_ref_atanh(double x) { return 0.5 * bp_log1p(bp_atanh_arg(x)); }
 
 }  // namespace ldpc

@@ -413,6 +413,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.xor_input = r.xor_input;
     a.max_iter = dec->max_iter;
     a.fail_bit = r.fail_bit;
+    a.profile = std::getenv("LDPC_HIP_BP_PROFILE") != nullptr;
     a.prior = std::log((1.0 - dec->p) / dec->p);   // belief_propagation.rs:38
     a.seed = r.seed;
     a.first_shot = r.first_shot;
@@ -441,6 +442,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.dsl = (uint64_t *)base;
     base += groups * (size_t)g.n * 8;
     a.ssl = (uint64_t *)base;
+    base += groups * (size_t)g.m * 8;
+    a.esl = (uint64_t *)base;
     a.gap = r.gap;
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);

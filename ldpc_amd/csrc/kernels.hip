@@ -120,11 +120,23 @@ __global__ __launch_bounds__(256) void syndrome_kernel(DeviceGraph g, uint64_t n
     }
 }
 
-// test probe for bp_math.hpp: kind 0 = bp_tanh_half, 1 = bp_log1p
+// test probe for bp_math.hpp: kind 0 = bp_tanh_half, 1 = bp_log1p, 2 / 3 = OCML's tanh(x/2) / log1p,
+// 4 = bp_div_core(in[t], in[n + t]), 5 = bp_ref_atanh, 6 = bp_div_prod(in[t], in[n + t])
 __global__ __launch_bounds__(256) void bp_math_probe_kernel(int kind, uint64_t n, const double *in, double *out)
 {
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
-        out[t] = kind == 0 ? bp_tanh_half(in[t]) : kind == 1 ? bp_log1p(in[t]) : kind == 2 ? tanh(in[t] / 2.0) : log1p(in[t]);
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        double v;
+        switch (kind) {
+        case 0: v = bp_tanh_half(in[t]); break;
+        case 1: v = bp_log1p(in[t]); break;
+        case 2: v = tanh(in[t] / 2.0); break;
+        case 3: v = log1p(in[t]); break;
+        case 4: v = bp_div_core(in[t], in[n + t]); break;
+        case 5: v = bp_ref_atanh(in[t]); break;
+        default: v = bp_div_prod(in[t], in[n + t]); break;
+        }
+        out[t] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *flags, uint64_t n, unsigned long long *counters)
@@ -610,18 +622,18 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 
-// f64::atanh of the reference's toolchain: 0.5 * ln_1p(2x / (1 - x))
-__device__ inline double ref_atanh(double x) { return 0.5 * bp_log1p((2.0 * x) / (1.0 - x)); }
 
 // DC / DV > 0: every check has exactly DC bits / every bit exactly DV checks (regular code):
 // rows start at c*DC, loops are fully unrolled and the DC (DV) independent tanh / log1p chains of
 // a row interleave.  0 = any degrees (row pointers, runtime trip counts).
-template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(DeviceGraph g, BpArgs a)
+template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(DeviceGraph g, BpArgs a)
 {
     __shared__ uint32_t q[65];
     __shared__ unsigned long long sh_queue, sh_mism;
     __shared__ uint32_t sh_flag[2][64];   // per slot: [0] residual non-zero, [1] a logical generator anticommutes
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6, NT = blockDim.x;
+    // wv is wave-uniform: tell the compiler, so that check / bit / edge indices live in SGPRs and the
+    // graph arrays are read with scalar loads
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6, NT = blockDim.x;
     for (uint32_t i = tid; i < 65; i += NT) q[i] = a.gap.q[i];
     __syncthreads();
     const uint32_t n = g.n, m = g.m;
@@ -633,6 +645,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
     uint64_t *dw = a.dw + grp * (size_t)Wn * 64;
     uint64_t *dsl = a.dsl + grp * (size_t)n;
     uint64_t *ssl = a.ssl + grp * (size_t)m;
+    uint64_t *esl = a.esl + grp * (size_t)n;
     const double prior = a.prior;
 
     // replicated per-slot state (identical in all waves of the group)
@@ -641,6 +654,11 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
     uint64_t myi = 0;
     uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;   // accumulated by wave 0 only
 
+    // LDPC_HIP_BP_PROFILE: cycles of block 0 / wave 0 per phase (refill, stop test, harvest, checks, bits)
+    uint64_t prof[5] = {0, 0, 0, 0, 0}, tprev = a.profile ? __builtin_readcyclecounter() : 0;
+    auto lap = [&](int which) {
+        if (a.profile) { const uint64_t tnow = __builtin_readcyclecounter(); prof[which] += tnow - tprev; tprev = tnow; }
+    };
     for (;;) {
         // ---- refill idle slots from the device-wide queue (a.queue = shots handed out so far) ----
         {
@@ -661,10 +679,13 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
                 if (first_taken + (uint64_t)__builtin_popcountll(idle) >= a.n_shots) drained = true;
                 const uint64_t shot = a.first_shot + myi;
                 if (a.source != SRC_SYNDROMES) {
+                    // error words of the taken slots, kept per slot (ew, for the failure test) and transposed
+                    // to bit-sliced rows esl[b] = mask of the taken slots whose word has bit b (64 x 64 bit
+                    // transpose by ballot; only bit positions some slot has set are visited)
                     for (uint32_t w = wv; w < Wn; w += NW) {
+                        uint64_t x = 0;
                         if (take) {
                             uint32_t nb = bits_in_word(n, w);
-                            uint64_t x;
                             if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
                             else if (a.source == SRC_WORDS) {
                                 x = a.words_in[myi * Wn + w];
@@ -676,17 +697,25 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
                             }
                             ew[(size_t)w * 64 + lane] = x;
                         }
+                        const uint64_t anyv = wave_or64(x);
+                        uint64_t any = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(anyv >> 32)) << 32) |
+                                       __builtin_amdgcn_readfirstlane((uint32_t)anyv);
+                        uint64_t row = 0;
+                        while (any) {
+                            const uint32_t i = (uint32_t)__builtin_ctzll(any);
+                            any &= any - 1;
+                            const uint64_t mask = __ballot((x >> i) & 1ull);
+                            if (lane == i) row = mask;
+                        }
+                        const uint32_t b = w * 64 + lane;
+                        if (b < n) esl[b] = row;
                     }
                     __syncthreads();
-                    for (uint32_t c = wv; c < m; c += NW) {
-                        uint32_t par = 0;
-                        const uint32_t e0 = g.h_ptr[c], e1 = g.h_ptr[c + 1];
-                        for (uint32_t e = e0; e < e1; e++) {
-                            uint32_t b = g.h_idx[e];
-                            if (take) par ^= (uint32_t)(ew[(size_t)(b >> 6) * 64 + lane] >> (b & 63)) & 1u;
-                        }
-                        uint64_t mask = __ballot(take && par);
-                        if (lane == 0) ssl[c] = (ssl[c] & ~takemask) | mask;
+                    // syndromes of the taken slots, all at once: XOR of the bit-sliced rows of a check's bits
+                    for (uint32_t c = tid; c < m; c += NT) {
+                        uint64_t par = 0;
+                        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) par ^= esl[g.h_idx[e]];
+                        ssl[c] = (ssl[c] & ~takemask) | (par & takemask);
                     }
                 } else {
                     for (uint32_t c = wv; c < m; c += NW) {
@@ -709,6 +738,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
         }
         const uint64_t actmask = __ballot(active);
         if (!actmask) break;
+        lap(0);
 
         // ---- stop test (belief_propagation.rs:26-27), bit-sliced over the 64 slots: the threads of
         // the group split the checks, each XORs whole 64-slot words; partial masks are OR-ed in LDS
@@ -729,6 +759,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
         const bool conv = !((mism >> lane) & 1ull);
         const bool done = active && (conv || iter >= a.max_iter);
         const uint64_t donemask = __ballot(done);
+        lap(1);
 
         if (donemask) {
             // ---- harvest ------------------------------------------------------
@@ -781,6 +812,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
                 active = false;
             }
             __syncthreads();
+            lap(2);
             if (!drained) continue;     // refill before spending an iteration
             if (!__ballot(active)) break;
         }
@@ -810,9 +842,35 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
                 double prod = 1.0;
 #pragma unroll
                 for (int j = 0; j < DC; j++) prod *= t[j];
+                // 2 atanh(prod / t_j) for the DC edges: the common-case arithmetic of all edges first (DC
+                // independent chains to interleave), the rare operands patched in blocks a wave seldom enters
+                double y[DC];
+                bool rare = false;
 #pragma unroll
                 for (int j = 0; j < DC; j++) {
-                    double v = 2.0 * ref_atanh(prod / t[j]);
+                    y[j] = bp_div_core(prod, t[j]);
+                    rare |= bp_exponent_out_of_band(t[j]);
+                }
+                if (__builtin_expect(__ballot(rare) != 0, 0)) {
+#pragma unroll
+                    for (int j = 0; j < DC; j++) y[j] = prod / t[j];
+                }
+                rare = false;
+#pragma unroll
+                for (int j = 0; j < DC; j++) {
+                    y[j] = bp_atanh_arg(y[j]);
+                    rare |= bp_log1p_is_special(y[j]);
+                }
+                double l[DC];
+#pragma unroll
+                for (int j = 0; j < DC; j++) l[j] = bp_log1p_main(y[j]);
+                if (__builtin_expect(__ballot(rare) != 0, 0)) {
+#pragma unroll
+                    for (int j = 0; j < DC; j++) l[j] = bp_log1p_fix(y[j], l[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < DC; j++) {
+                    double v = 2.0 * (0.5 * l[j]);
                     if (sbit) v *= -1.0;
                     if (active) chkm[(e0 + j) * 64 + lane] = v;
                 }
@@ -834,7 +892,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
 #pragma unroll
                     for (uint32_t j = 0; j < REG_DEG; j++)
                         if (j < dc) {
-                            double v = 2.0 * ref_atanh(prod / t[j]);
+                            double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, t[j]));
                             if (sbit) v *= -1.0;
                             if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                         }
@@ -846,7 +904,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
                     }
                     for (uint32_t j = 0; j < dc; j++) {
                         double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        double v = 2.0 * ref_atanh(prod / bp_tanh_half(x));
+                        double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, bp_tanh_half(x)));
                         if (sbit) v *= -1.0;
                         if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                     }
@@ -854,6 +912,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
             }
         }
         __syncthreads();
+        lap(3);
         // update_bits (:168-180) + hard decision (:100-113): the waves take 64-bit chunks round-robin
         for (uint32_t chunk = wv; chunk < Wn; chunk += NW) {
             uint64_t dacc = 0, slice = 0;
@@ -934,7 +993,11 @@ template <int DC, int DV> __global__ __launch_bounds__(512) void bp_kernel(Devic
         }
         if (active) { iter++; fresh = false; }
         __syncthreads();
+        lap(4);
     }
+    if (a.profile && blockIdx.x == 0 && tid == 0)
+        printf("bp profile (block 0, wave 0) cycles: refill %llu stop-test %llu harvest %llu checks %llu bits %llu\n", (unsigned long long)prof[0],
+               (unsigned long long)prof[1], (unsigned long long)prof[2], (unsigned long long)prof[3], (unsigned long long)prof[4]);
     if (wv == 0) {
         c_shots = wave_sum64(c_shots); c_fail = wave_sum64(c_fail); c_det = wave_sum64(c_det); c_work = wave_sum64(c_work);
         if (lane == 0 && a.counters) {
@@ -965,7 +1028,7 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap)
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g)
 {
     size_t Wn = (g.n + 63) / 64;
-    return 2 * (size_t)g.E * 64 * sizeof(double) + 2 * Wn * 64 * sizeof(uint64_t) + ((size_t)g.n + g.m) * sizeof(uint64_t);
+    return 2 * (size_t)g.E * 64 * sizeof(double) + 2 * Wn * 64 * sizeof(uint64_t) + (2 * (size_t)g.n + g.m) * sizeof(uint64_t);
 }
 
 hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,

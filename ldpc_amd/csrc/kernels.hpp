@@ -45,6 +45,7 @@ struct BpArgs {
     int xor_input;              // decode(): output = input ^ correction
     uint32_t max_iter;
     uint32_t fail_bit;          // OR-ed into failed_out on failure
+    uint32_t profile;           // diagnostics (LDPC_HIP_BP_PROFILE): block 0 prints its cycles per phase
     double prior;               // ln((1-p)/p), belief_propagation.rs:38
     uint64_t seed, first_shot, n_shots;
     unsigned long long *queue;  // device counter, zero at launch: shots handed out so far
@@ -64,6 +65,7 @@ struct BpArgs {
     uint64_t *dw;               // [groups][Wn][64] hard decisions, packed per slot
     uint64_t *dsl;              // [groups][n]      hard decisions, bit-sliced over slots
     uint64_t *ssl;              // [groups][m]      syndromes, bit-sliced over slots
+    uint64_t *esl;              // [groups][n]      error words of the slots being refilled, bit-sliced (set-up scratch)
     GapTable gap;
 };
 
