@@ -49,17 +49,17 @@ __device__ inline double bp_div_prod(double prod, double t)
 // faster than libm-to-libm differences do).  So E is carried as an unevaluated sum Eh + El (Cody-Waite
 // reduction |x| = k ln2 - r, e^r = 1 + r + r^2 Q(r) with the rounding errors of the last additions kept),
 // numerator and denominator likewise, and the quotient gets one correction step.  For k = 0 the same
-// formulas give 1 - E = -(expm1 part) without cancellation, so one path serves every |x| >= 2^-8;
-// below that the odd Taylor series h - h^3/3 + 2h^5/15 (h = x/2, next term < 2^-58 relative) is used.
+// formulas give 1 - E = -(expm1 part) without cancellation, so one path serves every x.
 // Measured: <= 0.55 ulp for |x| >= 0.5, <= 0.64 ulp below (the uncompensated rounding of r^2 Q(r) shows
 // when r is near ln2/2), 96-100 % correctly rounded; glibc's tanh: <= 1.15 ulp, about 80 %.
 __device__ inline double bp_tanh_half(double x)
 {
-    const double a = fmin(fabs(x), 64.0);   // tanh(32) is 1.0 in f64 already; keeps 2^-k normal
-    const double kd = rint(a * 1.4426950408889634074);
+    const double ax = fabs(x);
+    const double a = ax > 64.0 ? 64.0 : ax;       // tanh(32) is 1.0 in f64 already; keeps 2^-k normal; NaN stays NaN
+    const double kn = rint(a * -1.4426950408889634074);   // -k
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double rh = kd * ln2_hi - a;            // exact (Cody-Waite, Sterbenz)
-    const double rl = kd * ln2_lo;
+    const double rh = -(kn * ln2_hi) - a;         // k ln2_hi - a, exact (Cody-Waite, Sterbenz)
+    const double rl = -(kn * ln2_lo);
     const double r = rh + rl;
     const double rc = (rh - r) + rl;              // r + rc = rh + rl
     double q = 1.0 / 6227020800.0;                // 1/13!
@@ -79,21 +79,19 @@ __device__ inline double bp_tanh_half(double x)
     const double pl = ((r - ph) + r2q) + fma(rc, ph, rc);   // low part of e^(r+rc) - 1
     const double sh = 1.0 + ph;
     const double sl = ((1.0 - sh) + ph) + pl;     // e^(r+rc) = sh + sl
-    const int k = -(int)kd;
+    const int k = (int)kn;
     const double eh = ldexp(sh, k), el = ldexp(sl, k);      // E = e^-a
     const double nh = 1.0 - eh, nl = ((1.0 - nh) - eh) - el;
     const double dh = 1.0 + eh, dl = ((1.0 - dh) + eh) + el;
-    // (nh + nl) / (dh + dl): dh in [1, 2], 0 <= nh <= 1, no special operands
+    // (nh + nl) / (dh + dl): dh in [1, 2], 0 <= nh <= 1, no special operands.  For tiny |x| nh holds
+    // few bits (or none) and the residual step carries the result: x = 1e-300 gives q0 = 0, rem = x
     double rd = __builtin_amdgcn_rcp(dh);
     rd = fma(fma(-dh, rd, 1.0), rd, rd);
     const double q0 = nh * rd;
     const double rem = fma(-q0, dh, nh) + (nl - q0 * dl);
     const double big = fma(rem, rd, q0);
-    const double h = 0.5 * a, z = h * h;
-    const double tiny = fma(h * z, fma(z, 2.0 / 15.0, -1.0 / 3.0), h);
-    // tanh is odd: take the magnitude and put x's sign back (keeps -0)
-    const double t = copysign(a < 0.00390625 ? tiny : big, x);
-    return x != x ? x : t;
+    // tanh is odd: put x's sign back (keeps -0; a NaN stays a NaN)
+    return copysign(big, x);
 }
 
 // log1p(x), argument reduction and kernel polynomial of the classic fdlibm scheme
@@ -111,7 +109,7 @@ __device__ inline double bp_log1p_main(double x)
     int hu = __double2hiint(u);
     int k = (hu >> 20) - 1023;
     // rounding error of 1 + x, relative to u (a few digits suffice when |c| <= ulp(u) is small against the result)
-    double c = (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);
+    double c = (fmin(x, 1.0) - (u - fmax(x, 1.0))) * __builtin_amdgcn_rcp(u);   // Fast2Sum, larger operand first
     hu &= 0x000fffff;
     const bool low = hu < 0x6a09e;                       // mantissa below sqrt(2)
     k += low ? 0 : 1;
@@ -157,14 +155,17 @@ __device__ inline double bp_log1p(double x)
 // f64::atanh of the reference's toolchain, 0.5 * ln_1p(2x / (1 - x)) (belief_propagation.rs:159), for
 // |x| <= 1 or NaN (x is a product of tanh values divided by one of its factors): 1 - x is 0 (x == 1:
 // the quotient is 2/0 = +inf), or lies in [2^-53, 2], where the fast division applies.
-// bp_ref_atanh = 0.5 * bp_log1p(bp_atanh_arg(x))
-__device__ inline double bp_atanh_arg(double x)
-{
-    const double d = 1.0 - x;
-    const double q = bp_div_core(2.0 * x, d);
-    return d == 0.0 ? __builtin_huge_val() : q;
-}
+// argument of ln_1p in the reference's atanh: 2x / (1 - x).  The fast quotient is wrong only for
+// x == 1 (1 - x == 0: the reference gets 2/0 = +inf, the fast path NaN): bp_atanh_arg_is_rare / _slow.
+__device__ inline double bp_atanh_arg(double x) { return bp_div_core(2.0 * x, 1.0 - x); }
+__device__ inline bool bp_atanh_arg_is_rare(double x) { return x == 1.0; }
+__device__ inline double bp_atanh_arg_slow(double x) { return (2.0 * x) / (1.0 - x); }
 
-__device__ inline double bp_ref_atanh(double x) { return 0.5 * bp_log1p(bp_atanh_arg(x)); }
+__device__ inline double bp_ref_atanh(double x)
+{
+    double q = bp_atanh_arg(x);
+    if (__builtin_expect(__ballot(bp_atanh_arg_is_rare(x)) != 0, 0)) q = bp_atanh_arg_slow(x);
+    return 0.5 * bp_log1p(q);
+}
 
 }  // namespace ldpc

@@ -837,42 +837,65 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 #pragma unroll
                     for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
                 }
+                // the edges are worked in batches of HB: enough independent chains to keep the pipeline
+                // busy next to the other waves of the SIMD, few enough to stay inside 128 registers
+                constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : 3;
 #pragma unroll
-                for (int j = 0; j < DC; j++) t[j] = bp_tanh_half(x[j]);
+                for (int h0 = 0; h0 < DC; h0 += HB) {
+#pragma unroll
+                    for (int j = h0; j < h0 + HB && j < DC; j++) t[j] = bp_tanh_half(x[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 double prod = 1.0;
 #pragma unroll
                 for (int j = 0; j < DC; j++) prod *= t[j];
-                // 2 atanh(prod / t_j) for the DC edges: the common-case arithmetic of all edges first (DC
-                // independent chains to interleave), the rare operands patched in blocks a wave seldom enters
-                double y[DC];
-                bool rare = false;
+                // 2 atanh(prod / t_j): the common-case arithmetic of a batch first, the rare operands patched
+                // in blocks a wave seldom enters.  |prod| <= |t_j| <= 1, so prod inside the normal band puts
+                // every t_j inside it (and a NaN or zero t_j makes prod NaN or zero): one test per check.
+                const bool odd_prod = bp_exponent_out_of_band(prod);
+                const uint32_t flip = sbit ? 0x80000000u : 0u;    // v *= -1.0 (belief_propagation.rs:160-162)
 #pragma unroll
-                for (int j = 0; j < DC; j++) {
-                    y[j] = bp_div_core(prod, t[j]);
-                    rare |= bp_exponent_out_of_band(t[j]);
-                }
-                if (__builtin_expect(__ballot(rare) != 0, 0)) {
+                for (int h0 = 0; h0 < DC; h0 += HB) {
+                    double y[HB], w[HB], l[HB];
 #pragma unroll
-                    for (int j = 0; j < DC; j++) y[j] = prod / t[j];
-                }
-                rare = false;
+                    for (int j = 0; j < HB; j++)
+                        if (h0 + j < DC) y[j] = bp_div_core(prod, t[h0 + j]);
+                    if (__builtin_expect(__ballot(odd_prod) != 0, 0)) {
 #pragma unroll
-                for (int j = 0; j < DC; j++) {
-                    y[j] = bp_atanh_arg(y[j]);
-                    rare |= bp_log1p_is_special(y[j]);
-                }
-                double l[DC];
+                        for (int j = 0; j < HB; j++)
+                            if (h0 + j < DC) y[j] = prod / t[h0 + j];
+                    }
+                    bool rare = false, special = false;
 #pragma unroll
-                for (int j = 0; j < DC; j++) l[j] = bp_log1p_main(y[j]);
-                if (__builtin_expect(__ballot(rare) != 0, 0)) {
+                    for (int j = 0; j < HB; j++)
+                        if (h0 + j < DC) {
+                            w[j] = bp_atanh_arg(y[j]);
+                            rare |= bp_atanh_arg_is_rare(y[j]);
+                        }
+                    if (__builtin_expect(__ballot(rare) != 0, 0)) {
 #pragma unroll
-                    for (int j = 0; j < DC; j++) l[j] = bp_log1p_fix(y[j], l[j]);
-                }
+                        for (int j = 0; j < HB; j++)
+                            if (h0 + j < DC) w[j] = bp_atanh_arg_slow(y[j]);
+                    }
 #pragma unroll
-                for (int j = 0; j < DC; j++) {
-                    double v = 2.0 * (0.5 * l[j]);
-                    if (sbit) v *= -1.0;
-                    if (active) chkm[(e0 + j) * 64 + lane] = v;
+                    for (int j = 0; j < HB; j++)
+                        if (h0 + j < DC) {
+                            special |= bp_log1p_is_special(w[j]);
+                            l[j] = bp_log1p_main(w[j]);
+                        }
+                    if (__builtin_expect(__ballot(special) != 0, 0)) {
+#pragma unroll
+                        for (int j = 0; j < HB; j++)
+                            if (h0 + j < DC) l[j] = bp_log1p_fix(w[j], l[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < HB; j++)
+                        if (h0 + j < DC) {
+                            const double v = 2.0 * (0.5 * l[j]);
+                            const double vs = __hiloint2double(__double2hiint(v) ^ (int)flip, __double2loint(v));
+                            if (active) chkm[(e0 + h0 + j) * 64 + lane] = vs;
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
@@ -918,39 +941,54 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             uint64_t dacc = 0, slice = 0;
             const uint32_t b0 = chunk * 64, b1 = b0 + 64 < n ? b0 + 64 : n;
             if constexpr (DV > 0) {
-                // software pipeline over the bits of the chunk: next bit's DV rows in flight
-                double vn[DV];
-                uint32_t edn[DV];
+                // the chunk's edge lists are fetched once, lane i holding those of bit b0 + i; the loop below
+                // reads them back as scalars (readlane), so every row address is scalar base + lane offset and
+                // no row load waits for an index load.  Software pipeline over blocks of BB bits: the BB*DV
+                // rows of the next block are in flight while the current block is summed and written back.
+                constexpr uint32_t BB = 4;
+                uint32_t myed[DV];
 #pragma unroll
-                for (int k = 0; k < DV; k++) {
-                    edn[k] = g.t_edge[b0 * (uint32_t)DV + k];
-                    vn[k] = chkm[(size_t)edn[k] * 64 + lane];
-                }
-                for (uint32_t b = b0; b < b1; b++) {
-                    double v[DV];
-                    uint32_t ed[DV];
+                for (int k = 0; k < DV; k++) myed[k] = b0 + lane < b1 ? g.t_edge[(b0 + lane) * (uint32_t)DV + k] : 0u;
+                const uint32_t nbits = b1 - b0;
+                double vn[BB][DV];
 #pragma unroll
-                    for (int k = 0; k < DV; k++) { v[k] = vn[k]; ed[k] = edn[k]; }
-                    if (b + 1 < b1) {
+                for (uint32_t i = 0; i < BB; i++)
+                    if (i < nbits) {
 #pragma unroll
-                        for (int k = 0; k < DV; k++) {
-                            edn[k] = g.t_edge[(b + 1) * (uint32_t)DV + k];
-                            vn[k] = chkm[(size_t)edn[k] * 64 + lane];
+                        for (int k = 0; k < DV; k++)
+                            vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i) * 64 + lane];
+                    }
+                for (uint32_t i0 = 0; i0 < nbits; i0 += BB) {
+                    double v[BB][DV];
+#pragma unroll
+                    for (uint32_t i = 0; i < BB; i++)
+#pragma unroll
+                        for (int k = 0; k < DV; k++) v[i][k] = vn[i][k];
+#pragma unroll
+                    for (uint32_t i = 0; i < BB; i++)
+                        if (i0 + BB + i < nbits) {
+#pragma unroll
+                            for (int k = 0; k < DV; k++)
+                                vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + BB + i) * 64 + lane];
                         }
-                    }
-                    double sum = 0.0, post = prior;
 #pragma unroll
-                    for (int k = 0; k < DV; k++) {
-                        sum += v[k];
-                        post += v[k];
-                    }
+                    for (uint32_t i = 0; i < BB; i++)
+                        if (i0 + i < nbits) {
+                            double sum = 0.0, post = prior;
 #pragma unroll
-                    for (int k = 0; k < DV; k++)
-                        if (active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
-                    const bool dec = post < 0.0;
-                    dacc |= (uint64_t)dec << (b & 63);
-                    uint64_t mask = __ballot(active && dec);
-                    if (lane == (b & 63)) slice = mask;
+                            for (int k = 0; k < DV; k++) {
+                                sum += v[i][k];
+                                post += v[i][k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < DV; k++)
+                                if (active)
+                                    bitsm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + i) * 64 + lane] = sum - v[i][k] + prior;
+                            const bool dec = post < 0.0;
+                            dacc |= (uint64_t)dec << (i0 + i);
+                            const uint64_t mask = __ballot(active && dec);
+                            if (lane == i0 + i) slice = mask;
+                        }
                 }
             } else {
                 for (uint32_t b = b0; b < b1; b++) {
