@@ -41,10 +41,11 @@ def cpu_baseline(code, budget_s=15.0):
     ptr, idx = code.csr()
     oc = orc.Code(code.len(), ptr=ptr.astype(np.int64), idx=idx.astype(np.uint32))
     threads = max(1, min(16, orc.max_threads(), os.cpu_count() or 1))
+    oc.mc_flip(P, NOISE_SEED, 0, threads, reference_style=True, nthreads=threads)      # warm the thread pool
     t0 = time.perf_counter()
-    oc.mc_flip(P, NOISE_SEED, 0, 2 * threads, reference_style=True, nthreads=threads)
-    per_shot = max(time.perf_counter() - t0, 1e-3) / (2 * threads)          # thread-seconds per shot / threads
-    shots = int(max(threads, min(20000, budget_s / per_shot)))
+    oc.mc_flip(P, NOISE_SEED, 0, 8 * threads, reference_style=True, nthreads=threads)
+    per_shot = max(time.perf_counter() - t0, 1e-3) / (8 * threads)          # wall seconds per shot, all threads busy
+    shots = int(max(threads, min(200000, budget_s / per_shot)))
     t0 = time.perf_counter()
     cnt = oc.mc_flip(P, NOISE_SEED, 0, shots, reference_style=True, nthreads=threads)
     dt = time.perf_counter() - t0
@@ -74,7 +75,7 @@ def measured_traffic(shots_per_launch):
         return None
 
 
-def bp_line(code, shots=1 << 18):
+def bp_line(code, shots=1 << 19):
     """Secondary measurement: the f64 BP kernel on the same code and channel (Monte-Carlo mode,
     max 100 iterations).  Algorithmic bytes = 32*E per shot-iteration."""
     import ldpc_amd
@@ -84,11 +85,17 @@ def bp_line(code, shots=1 << 18):
     cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
     ms = ldpc_amd.last_kernel_ms()
     gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bp_pmc.json")) as f:
+            traffic = json.load(f)["traffic_over_algorithmic"] * int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges()
+    except Exception:
+        pass
     return {"workload": "same code and channel, BpDecoder f64, max 100 iterations, %d shots" % shots,
             "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<6,3>", "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}}
 
 
 def main():

@@ -714,7 +714,15 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
                     // syndromes of the taken slots, all at once: XOR of the bit-sliced rows of a check's bits
                     for (uint32_t c = tid; c < m; c += NT) {
                         uint64_t par = 0;
-                        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) par ^= esl[g.h_idx[e]];
+                        if constexpr (DC > 0) {
+                            uint32_t bi[DC];
+#pragma unroll
+                            for (int j = 0; j < DC; j++) bi[j] = g.h_idx[c * (uint32_t)DC + j];
+#pragma unroll
+                            for (int j = 0; j < DC; j++) par ^= esl[bi[j]];
+                        } else {
+                            for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) par ^= esl[g.h_idx[e]];
+                        }
                         ssl[c] = (ssl[c] & ~takemask) | (par & takemask);
                     }
                 } else {
@@ -748,7 +756,17 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             uint64_t part = 0;
             for (uint32_t c = tid; c < m; c += NT) {
                 uint64_t x = ssl[c];
-                for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= dsl[g.h_idx[e]];
+                if constexpr (DC > 0) {
+                    // regular rows: the DC indices, then the DC rows, are fetched together (two memory
+                    // latencies per check instead of 2 DC)
+                    uint32_t bi[DC];
+#pragma unroll
+                    for (int j = 0; j < DC; j++) bi[j] = g.h_idx[c * (uint32_t)DC + j];
+#pragma unroll
+                    for (int j = 0; j < DC; j++) x ^= dsl[bi[j]];
+                } else {
+                    for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= dsl[g.h_idx[e]];
+                }
                 part |= x;
             }
             part = wave_or64(part);
