@@ -98,6 +98,26 @@ def bp_line(code, shots=1 << 19):
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}}
 
 
+def bp_c5_line(shots=17664):
+    """Secondary measurement: configs[4], (3,6)-regular n = 10^6 (3 GB of f64 messages per 64-shot group: the
+    streamed BP form, one grid-wide kernel per phase).  Time = hipEvents around the whole host-driven loop."""
+    import ldpc_amd
+    from ldpc_amd import BpDecoder, LinearCode
+    code = LinearCode.random_regular_code(1000000, 500000, 3, 6, seed=CODE_SEED)
+    dec = BpDecoder(code, P, 100)
+    dec.mc_run(P, NOISE_SEED, 1 << 40, 64)
+    cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
+    ms = ldpc_amd.last_kernel_ms()
+    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
+    return {"workload": "configs[4]: random (3,6)-regular LDPC n=1000000 m=500000, BSC p=0.02, BpDecoder f64, max 100 "
+                        "iterations, %d shots" % shots,
+            "shots_per_s": shots / (ms * 1e-3), "kernels": "bps_iterate<6,3> + set-up / stop-test / harvest kernels",
+            "loop_ms": ms, "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots,
+            "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +215,7 @@ def main():
             line["cpu_baseline"] = cb
         if not args.no_bp and world == 1:
             line["bp"] = bp_line(code)
+            line["bp_c5"] = bp_c5_line()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

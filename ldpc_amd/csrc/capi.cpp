@@ -194,7 +194,7 @@ struct ldpc_bp_decoder {
     double p = 0.5;
     uint32_t max_iter = 0;
     std::mutex mu;
-    DeviceBuffer counters, workspace;
+    DeviceBuffer counters, workspace, stream_state;
     int reg_dc = 0, reg_dv = 0;   // common check / bit degree when the code is regular, else 0
 };
 
@@ -402,8 +402,18 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
                                            " bytes of message storage, more than the device can give");
     uint64_t groups = std::min<uint64_t>(max_groups, (r.n_shots + 63) / 64);
     groups = std::max<uint64_t>(groups, 1);
+    // Streamed form (one grid-wide kernel per phase, all CUs on every group) when memory, not the shot count,
+    // leaves the persistent kernel with fewer workgroups than half the CUs: C5, 3 GB of messages per group.
+    const uint64_t by_memory = budget / std::max<size_t>(per_group, 1);
+    bool stream = by_memory < 128;
+    if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) {   // A/B and test aid
+        if (!std::strcmp(e, "stream")) stream = true;
+        else if (!std::strcmp(e, "persistent")) stream = false;
+    }
+    if (stream && r.test == TEST_LOGICAL) stream = false;   // CSS failure test: persistent kernel only
+    if (stream) groups = std::min<uint64_t>(std::min<uint64_t>(by_memory, 4096), std::max<uint64_t>((r.n_shots + 63) / 64, 1));
     if (std::getenv("LDPC_HIP_DEBUG"))
-        std::fprintf(stderr, "[ldpc_hip] bp: E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", g.E, waves,
+        std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
     HIP_TRY(dec->workspace.reserve(per_group * groups));
 
@@ -447,7 +457,13 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.gap = r.gap;
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);
-    HIP_TRY(launch_bp(g, a, (uint32_t)groups, waves, dec->reg_dc, dec->reg_dv, g_stream));
+    if (stream) {
+        HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
+        uint64_t rounds = 0;
+        HIP_TRY(bp_stream_run(g, a, dec->stream_state.as<char>(), (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds));
+        if (std::getenv("LDPC_HIP_DEBUG")) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu rounds\n", (unsigned long long)rounds);
+    } else
+        HIP_TRY(launch_bp(g, a, (uint32_t)groups, waves, dec->reg_dc, dec->reg_dv, g_stream));
     if (timer) timer->stop_and_store();
     if (counters_out) return read_counters(dec->counters, counters_out);
     HIP_TRY(hipStreamSynchronize(g_stream));

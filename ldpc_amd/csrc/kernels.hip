@@ -623,6 +623,170 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 
 
+// update_checks for one check of degree DC (belief_propagation.rs:150-166): x = the incoming bit messages in
+// ascending bit order, out = the outgoing check messages, flip = 0x80000000 when the check's syndrome bit is
+// set (the reference multiplies by -1.0, :160-162).  The edges are worked in batches of HB: enough independent
+// chains to keep the pipeline busy next to the other waves of the SIMD, few enough to stay inside 128 registers.
+template <int DC> __device__ inline void bp_check_row(const double (&x)[DC], uint32_t flip, double (&out)[DC])
+{
+    constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : 3;
+    double t[DC];
+#pragma unroll
+    for (int h0 = 0; h0 < DC; h0 += HB) {
+#pragma unroll
+        for (int j = h0; j < h0 + HB && j < DC; j++) t[j] = bp_tanh_half(x[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double prod = 1.0;
+#pragma unroll
+    for (int j = 0; j < DC; j++) prod *= t[j];
+    // 2 atanh(prod / t_j): the common-case arithmetic of a batch first, the rare operands patched in blocks a
+    // wave seldom enters.  |prod| <= |t_j| <= 1, so prod inside the normal band puts every t_j inside it (and
+    // a NaN or zero t_j makes prod NaN or zero): one test per check.
+    const bool odd_prod = bp_exponent_out_of_band(prod);
+#pragma unroll
+    for (int h0 = 0; h0 < DC; h0 += HB) {
+        double y[HB], w[HB], l[HB];
+#pragma unroll
+        for (int j = 0; j < HB; j++)
+            if (h0 + j < DC) y[j] = bp_div_core(prod, t[h0 + j]);
+        if (__builtin_expect(__ballot(odd_prod) != 0, 0)) {
+#pragma unroll
+            for (int j = 0; j < HB; j++)
+                if (h0 + j < DC) y[j] = prod / t[h0 + j];
+        }
+        bool rare = false, special = false;
+#pragma unroll
+        for (int j = 0; j < HB; j++)
+            if (h0 + j < DC) {
+                w[j] = bp_atanh_arg(y[j]);
+                rare |= bp_atanh_arg_is_rare(y[j]);
+            }
+        if (__builtin_expect(__ballot(rare) != 0, 0)) {
+#pragma unroll
+            for (int j = 0; j < HB; j++)
+                if (h0 + j < DC) w[j] = bp_atanh_arg_slow(y[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < HB; j++)
+            if (h0 + j < DC) {
+                special |= bp_log1p_is_special(w[j]);
+                l[j] = bp_log1p_main(w[j]);
+            }
+        if (__builtin_expect(__ballot(special) != 0, 0)) {
+#pragma unroll
+            for (int j = 0; j < HB; j++)
+                if (h0 + j < DC) l[j] = bp_log1p_fix(w[j], l[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < HB; j++)
+            if (h0 + j < DC) {
+                const double v = 2.0 * (0.5 * l[j]);
+                out[h0 + j] = __hiloint2double(__double2hiint(v) ^ (int)flip, __double2loint(v));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// update_bits (belief_propagation.rs:168-180) + hard decision (:100-113) for the 64 bits of one chunk, all 64
+// slots of the group (lane = slot).  DV > 0: every bit has exactly DV checks.
+template <int DV>
+__device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint32_t lane, bool active, uint64_t actmask,
+                                     double prior, const double *chkm, double *bitsm, uint64_t *dw, uint64_t *dsl)
+{
+    const uint32_t n = g.n;
+    uint64_t dacc = 0, slice = 0;
+    const uint32_t b0 = chunk * 64, b1 = b0 + 64 < n ? b0 + 64 : n;
+    if constexpr (DV > 0) {
+        // the chunk's edge lists are fetched once, lane i holding those of bit b0 + i; the loop below
+        // reads them back as scalars (readlane), so every row address is scalar base + lane offset and
+        // no row load waits for an index load.  Software pipeline over blocks of BB bits: the BB*DV
+        // rows of the next block are in flight while the current block is summed and written back.
+        constexpr uint32_t BB = 4;
+        uint32_t myed[DV];
+#pragma unroll
+        for (int k = 0; k < DV; k++) myed[k] = b0 + lane < b1 ? g.t_edge[(b0 + lane) * (uint32_t)DV + k] : 0u;
+        const uint32_t nbits = b1 - b0;
+        double vn[BB][DV];
+#pragma unroll
+        for (uint32_t i = 0; i < BB; i++)
+            if (i < nbits) {
+#pragma unroll
+                for (int k = 0; k < DV; k++)
+                    vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i) * 64 + lane];
+            }
+        for (uint32_t i0 = 0; i0 < nbits; i0 += BB) {
+            double v[BB][DV];
+#pragma unroll
+            for (uint32_t i = 0; i < BB; i++)
+#pragma unroll
+                for (int k = 0; k < DV; k++) v[i][k] = vn[i][k];
+#pragma unroll
+            for (uint32_t i = 0; i < BB; i++)
+                if (i0 + BB + i < nbits) {
+#pragma unroll
+                    for (int k = 0; k < DV; k++)
+                        vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + BB + i) * 64 + lane];
+                }
+#pragma unroll
+            for (uint32_t i = 0; i < BB; i++)
+                if (i0 + i < nbits) {
+                    double sum = 0.0, post = prior;
+#pragma unroll
+                    for (int k = 0; k < DV; k++) {
+                        sum += v[i][k];
+                        post += v[i][k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < DV; k++)
+                        if (active)
+                            bitsm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + i) * 64 + lane] = sum - v[i][k] + prior;
+                    const bool dec = post < 0.0;
+                    dacc |= (uint64_t)dec << (i0 + i);
+                    const uint64_t mask = __ballot(active && dec);
+                    if (lane == i0 + i) slice = mask;
+                }
+        }
+    } else {
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
+            double sum = 0.0, post = prior;
+            if (dv <= REG_DEG) {
+                double v[REG_DEG];
+                uint32_t ed[REG_DEG];
+#pragma unroll
+                for (uint32_t k = 0; k < REG_DEG; k++)
+                    if (k < dv) {
+                        ed[k] = g.t_edge[k0 + k];
+                        v[k] = chkm[(size_t)ed[k] * 64 + lane];
+                        sum += v[k];
+                        post += v[k];
+                    }
+#pragma unroll
+                for (uint32_t k = 0; k < REG_DEG; k++)
+                    if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+            } else {
+                for (uint32_t k = 0; k < dv; k++) {
+                    double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
+                    sum += v;
+                    post += v;
+                }
+                for (uint32_t k = 0; k < dv; k++) {
+                    size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
+                    if (active) bitsm[off] = sum - chkm[off] + prior;
+                }
+            }
+            const bool dec = post < 0.0;
+            dacc |= (uint64_t)dec << (b & 63);
+            uint64_t mask = __ballot(active && dec);
+            if (lane == (b & 63)) slice = mask;
+        }
+    }
+    if (active) dw[(size_t)chunk * 64 + lane] = dacc;
+    const uint32_t bb = b0 + lane;
+    if (bb < b1) dsl[bb] = (dsl[bb] & ~actmask) | slice;
+}
+
 // DC / DV > 0: every check has exactly DC bits / every bit exactly DV checks (regular code):
 // rows start at c*DC, loops are fully unrolled and the DC (DV) independent tanh / log1p chains of
 // a row interleave.  0 = any degrees (row pointers, runtime trip counts).
@@ -848,73 +1012,18 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             for (uint32_t c = wv; c < m; c += NW) {
                 const size_t e0 = (size_t)c * DC;
                 const bool sbit = (ssl[c] >> lane) & 1ull;
-                double x[DC], t[DC];
+                double x[DC];
 #pragma unroll
                 for (int j = 0; j < DC; j++) x[j] = xn[j];
                 if (c + NW < m) {
 #pragma unroll
                     for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
                 }
-                // the edges are worked in batches of HB: enough independent chains to keep the pipeline
-                // busy next to the other waves of the SIMD, few enough to stay inside 128 registers
-                constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : 3;
+                double out[DC];
+                bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
 #pragma unroll
-                for (int h0 = 0; h0 < DC; h0 += HB) {
-#pragma unroll
-                    for (int j = h0; j < h0 + HB && j < DC; j++) t[j] = bp_tanh_half(x[j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                double prod = 1.0;
-#pragma unroll
-                for (int j = 0; j < DC; j++) prod *= t[j];
-                // 2 atanh(prod / t_j): the common-case arithmetic of a batch first, the rare operands patched
-                // in blocks a wave seldom enters.  |prod| <= |t_j| <= 1, so prod inside the normal band puts
-                // every t_j inside it (and a NaN or zero t_j makes prod NaN or zero): one test per check.
-                const bool odd_prod = bp_exponent_out_of_band(prod);
-                const uint32_t flip = sbit ? 0x80000000u : 0u;    // v *= -1.0 (belief_propagation.rs:160-162)
-#pragma unroll
-                for (int h0 = 0; h0 < DC; h0 += HB) {
-                    double y[HB], w[HB], l[HB];
-#pragma unroll
-                    for (int j = 0; j < HB; j++)
-                        if (h0 + j < DC) y[j] = bp_div_core(prod, t[h0 + j]);
-                    if (__builtin_expect(__ballot(odd_prod) != 0, 0)) {
-#pragma unroll
-                        for (int j = 0; j < HB; j++)
-                            if (h0 + j < DC) y[j] = prod / t[h0 + j];
-                    }
-                    bool rare = false, special = false;
-#pragma unroll
-                    for (int j = 0; j < HB; j++)
-                        if (h0 + j < DC) {
-                            w[j] = bp_atanh_arg(y[j]);
-                            rare |= bp_atanh_arg_is_rare(y[j]);
-                        }
-                    if (__builtin_expect(__ballot(rare) != 0, 0)) {
-#pragma unroll
-                        for (int j = 0; j < HB; j++)
-                            if (h0 + j < DC) w[j] = bp_atanh_arg_slow(y[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < HB; j++)
-                        if (h0 + j < DC) {
-                            special |= bp_log1p_is_special(w[j]);
-                            l[j] = bp_log1p_main(w[j]);
-                        }
-                    if (__builtin_expect(__ballot(special) != 0, 0)) {
-#pragma unroll
-                        for (int j = 0; j < HB; j++)
-                            if (h0 + j < DC) l[j] = bp_log1p_fix(w[j], l[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < HB; j++)
-                        if (h0 + j < DC) {
-                            const double v = 2.0 * (0.5 * l[j]);
-                            const double vs = __hiloint2double(__double2hiint(v) ^ (int)flip, __double2loint(v));
-                            if (active) chkm[(e0 + h0 + j) * 64 + lane] = vs;
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int j = 0; j < DC; j++)
+                    if (active) chkm[(e0 + j) * 64 + lane] = out[j];
             }
         } else {
             for (uint32_t c = wv; c < m; c += NW) {
@@ -955,98 +1064,8 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
         __syncthreads();
         lap(3);
         // update_bits (:168-180) + hard decision (:100-113): the waves take 64-bit chunks round-robin
-        for (uint32_t chunk = wv; chunk < Wn; chunk += NW) {
-            uint64_t dacc = 0, slice = 0;
-            const uint32_t b0 = chunk * 64, b1 = b0 + 64 < n ? b0 + 64 : n;
-            if constexpr (DV > 0) {
-                // the chunk's edge lists are fetched once, lane i holding those of bit b0 + i; the loop below
-                // reads them back as scalars (readlane), so every row address is scalar base + lane offset and
-                // no row load waits for an index load.  Software pipeline over blocks of BB bits: the BB*DV
-                // rows of the next block are in flight while the current block is summed and written back.
-                constexpr uint32_t BB = 4;
-                uint32_t myed[DV];
-#pragma unroll
-                for (int k = 0; k < DV; k++) myed[k] = b0 + lane < b1 ? g.t_edge[(b0 + lane) * (uint32_t)DV + k] : 0u;
-                const uint32_t nbits = b1 - b0;
-                double vn[BB][DV];
-#pragma unroll
-                for (uint32_t i = 0; i < BB; i++)
-                    if (i < nbits) {
-#pragma unroll
-                        for (int k = 0; k < DV; k++)
-                            vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i) * 64 + lane];
-                    }
-                for (uint32_t i0 = 0; i0 < nbits; i0 += BB) {
-                    double v[BB][DV];
-#pragma unroll
-                    for (uint32_t i = 0; i < BB; i++)
-#pragma unroll
-                        for (int k = 0; k < DV; k++) v[i][k] = vn[i][k];
-#pragma unroll
-                    for (uint32_t i = 0; i < BB; i++)
-                        if (i0 + BB + i < nbits) {
-#pragma unroll
-                            for (int k = 0; k < DV; k++)
-                                vn[i][k] = chkm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + BB + i) * 64 + lane];
-                        }
-#pragma unroll
-                    for (uint32_t i = 0; i < BB; i++)
-                        if (i0 + i < nbits) {
-                            double sum = 0.0, post = prior;
-#pragma unroll
-                            for (int k = 0; k < DV; k++) {
-                                sum += v[i][k];
-                                post += v[i][k];
-                            }
-#pragma unroll
-                            for (int k = 0; k < DV; k++)
-                                if (active)
-                                    bitsm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + i) * 64 + lane] = sum - v[i][k] + prior;
-                            const bool dec = post < 0.0;
-                            dacc |= (uint64_t)dec << (i0 + i);
-                            const uint64_t mask = __ballot(active && dec);
-                            if (lane == i0 + i) slice = mask;
-                        }
-                }
-            } else {
-                for (uint32_t b = b0; b < b1; b++) {
-                    const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
-                    double sum = 0.0, post = prior;
-                    if (dv <= REG_DEG) {
-                        double v[REG_DEG];
-                        uint32_t ed[REG_DEG];
-#pragma unroll
-                        for (uint32_t k = 0; k < REG_DEG; k++)
-                            if (k < dv) {
-                                ed[k] = g.t_edge[k0 + k];
-                                v[k] = chkm[(size_t)ed[k] * 64 + lane];
-                                sum += v[k];
-                                post += v[k];
-                            }
-#pragma unroll
-                        for (uint32_t k = 0; k < REG_DEG; k++)
-                            if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
-                    } else {
-                        for (uint32_t k = 0; k < dv; k++) {
-                            double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
-                            sum += v;
-                            post += v;
-                        }
-                        for (uint32_t k = 0; k < dv; k++) {
-                            size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
-                            if (active) bitsm[off] = sum - chkm[off] + prior;
-                        }
-                    }
-                    const bool dec = post < 0.0;
-                    dacc |= (uint64_t)dec << (b & 63);
-                    uint64_t mask = __ballot(active && dec);
-                    if (lane == (b & 63)) slice = mask;
-                }
-            }
-            if (active) dw[(size_t)chunk * 64 + lane] = dacc;
-            const uint32_t bb = b0 + lane;
-            if (bb < b1) dsl[bb] = (dsl[bb] & ~actmask) | slice;
-        }
+        for (uint32_t chunk = wv; chunk < Wn; chunk += NW)
+            bp_bits_chunk<DV>(g, chunk, lane, active, actmask, prior, chkm, bitsm, dw, dsl);
         if (active) { iter++; fresh = false; }
         __syncthreads();
         lap(4);
@@ -1066,6 +1085,344 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             if (c_fail - c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
             if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Belief propagation, streamed form for codes whose message arrays are so large
+// that memory allows fewer 64-shot groups than the chip has room for workgroups
+// (C5: n = 10^6, 3 GB per group).  The same data layout and arithmetic as
+// bp_kernel, but every phase is a grid-wide kernel over (group, part): all CUs
+// work on every group, kernel boundaries are the barriers, the slot state lives
+// in global memory (BpsState) and the host only reads one counter per round.
+// ---------------------------------------------------------------------------
+constexpr uint32_t BPS_THREADS = 256, BPS_WAVES = BPS_THREADS / 64;
+
+struct BpsGroup {
+    double *bitsm, *chkm;
+    uint64_t *ew, *dw, *dsl, *ssl, *esl;
+};
+
+__device__ inline BpsGroup bps_group(const DeviceGraph &g, const BpArgs &a, size_t grp)
+{
+    const size_t Wn = (g.n + 63) / 64;
+    BpsGroup r;
+    r.bitsm = a.msg + grp * 2 * (size_t)g.E * 64;
+    r.chkm = r.bitsm + (size_t)g.E * 64;
+    r.ew = a.ew + grp * Wn * 64;
+    r.dw = a.dw + grp * Wn * 64;
+    r.dsl = a.dsl + grp * (size_t)g.n;
+    r.ssl = a.ssl + grp * (size_t)g.m;
+    r.esl = a.esl + grp * (size_t)g.n;
+    return r;
+}
+
+// slots whose shot stops now: converged (stop test) or at the iteration cap (belief_propagation.rs:26-27)
+__device__ inline uint64_t bps_done_mask(const BpArgs &a, const BpsState &s, size_t grp, uint32_t lane, bool &conv)
+{
+    const bool active = (s.act[grp] >> lane) & 1ull;
+    conv = !((s.mism[grp] >> lane) & 1ull);
+    return __ballot(active && (conv || s.iter[grp * 64 + lane] >= a.max_iter));
+}
+
+// one wave per group: hand idle slots their next shots
+__global__ __launch_bounds__(64) void bps_ctl_refill(BpArgs a, BpsState s, uint32_t g0)
+{
+    const size_t grp = g0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t act = s.act[grp], idle = ~act;
+    uint64_t first = a.n_shots;
+    if (idle) {
+        unsigned long long f = 0;
+        if (lane == 0) f = atomicAdd(a.queue, (unsigned long long)__builtin_popcountll(idle));
+        first = readlane64(f, 0);
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+    const bool take = ((idle >> lane) & 1ull) && first < a.n_shots && first + rank < a.n_shots;
+    const uint64_t takemask = __ballot(take);
+    if (take) {
+        s.myi[grp * 64 + lane] = first + rank;
+        s.iter[grp * 64 + lane] = 0;
+    }
+    s.flags[grp * 64 + lane] = 0;
+    if (lane == 0) {
+        s.take[grp] = takemask;
+        s.act[grp] = act | takemask;
+        s.fresh[grp] = (s.fresh[grp] & act) | takemask;
+        s.mism[grp] = 0;
+    }
+}
+
+// (group, part): error words of the taken slots, bit-sliced rows, initial decisions
+__global__ __launch_bounds__(BPS_THREADS) void bps_setup_words(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0)
+{
+    __shared__ uint32_t q[65];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t grp = g0 + blockIdx.x / parts;
+    const uint32_t part = blockIdx.x % parts;
+    const uint64_t takemask = s.take[grp];
+    if (!takemask) return;
+    for (uint32_t i = tid; i < 65; i += BPS_THREADS) q[i] = a.gap.q[i];
+    __syncthreads();
+    const BpsGroup G = bps_group(g, a, grp);
+    const uint32_t n = g.n, Wn = (n + 63) / 64, Wm = (g.m + 63) / 64;
+    const bool take = (takemask >> lane) & 1ull;
+    const uint64_t myi = take ? s.myi[grp * 64 + lane] : 0, shot = a.first_shot + myi;
+    const bool init = a.prior < 0.0;   // decision before the first update: posterior = prior
+    for (uint32_t w = part * BPS_WAVES + wv; w < Wn; w += parts * BPS_WAVES) {
+        const uint32_t nb = bits_in_word(n, w);
+        const uint32_t b = w * 64 + lane;
+        if (a.source != SRC_SYNDROMES) {
+            uint64_t x = 0;
+            if (take) {
+                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+                else if (a.source == SRC_WORDS) {
+                    x = a.words_in[myi * Wn + w];
+                    if (nb < 64) x &= (1ull << nb) - 1;
+                } else {
+                    uint64_t xx, zz;
+                    depol_word(q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
+                    x = a.source == SRC_DEPOL_X ? xx : zz;
+                }
+                G.ew[(size_t)w * 64 + lane] = x;
+            }
+            const uint64_t anyv = wave_or64(x);
+            uint64_t any = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(anyv >> 32)) << 32) |
+                           __builtin_amdgcn_readfirstlane((uint32_t)anyv);
+            uint64_t row = 0;
+            while (any) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(any);
+                any &= any - 1;
+                const uint64_t mask = __ballot((x >> i) & 1ull);
+                if (lane == i) row = mask;
+            }
+            if (b < n) G.esl[b] = row;
+        }
+        if (b < n) G.dsl[b] = (G.dsl[b] & ~takemask) | (init ? takemask : 0ull);
+        if (take) G.dw[(size_t)w * 64 + lane] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
+    }
+    if (a.source == SRC_SYNDROMES) {
+        // given syndromes: the same ballot transpose, word by word, straight into the bit-sliced rows
+        for (uint32_t w = part * BPS_WAVES + wv; w < Wm; w += parts * BPS_WAVES) {
+            uint64_t x = take ? a.synd_in[myi * Wm + w] : 0;
+            const uint64_t anyv = wave_or64(x);
+            uint64_t any = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(anyv >> 32)) << 32) |
+                           __builtin_amdgcn_readfirstlane((uint32_t)anyv);
+            uint64_t row = 0;
+            while (any) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(any);
+                any &= any - 1;
+                const uint64_t mask = __ballot((x >> i) & 1ull);
+                if (lane == i) row = mask;
+            }
+            const uint32_t c = w * 64 + lane;
+            if (c < g.m) G.ssl[c] = (G.ssl[c] & ~takemask) | (row & takemask);
+        }
+    }
+}
+
+// (group, part): syndromes of the taken slots from the bit-sliced error rows, thread per check
+__global__ __launch_bounds__(BPS_THREADS) void bps_setup_synd(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0)
+{
+    const size_t grp = g0 + blockIdx.x / parts;
+    const uint32_t part = blockIdx.x % parts;
+    const uint64_t takemask = s.take[grp];
+    if (!takemask || a.source == SRC_SYNDROMES) return;
+    const BpsGroup G = bps_group(g, a, grp);
+    for (uint32_t c = part * BPS_THREADS + threadIdx.x; c < g.m; c += parts * BPS_THREADS) {
+        uint64_t par = 0;
+        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) par ^= G.esl[g.h_idx[e]];
+        G.ssl[c] = (G.ssl[c] & ~takemask) | (par & takemask);
+    }
+}
+
+// (group, part): stop test, bit-sliced; only_fresh: groups that took no shot this round are skipped
+__global__ __launch_bounds__(BPS_THREADS) void bps_stop(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0, int only_fresh)
+{
+    const size_t grp = g0 + blockIdx.x / parts;
+    const uint32_t part = blockIdx.x % parts;
+    if (!s.act[grp] || (only_fresh && !s.take[grp])) return;
+    const BpsGroup G = bps_group(g, a, grp);
+    uint64_t acc = 0;
+    for (uint32_t c = part * BPS_THREADS + threadIdx.x; c < g.m; c += parts * BPS_THREADS) {
+        uint64_t x = G.ssl[c];
+        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= G.dsl[g.h_idx[e]];
+        acc |= x;
+    }
+    acc = wave_or64(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long *)&s.mism[grp], (unsigned long long)acc);
+}
+
+// (group, part): outputs and residual test of the slots that stop now
+__global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0, int only_fresh)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t grp = g0 + blockIdx.x / parts;
+    const uint32_t part = blockIdx.x % parts;
+    if (!s.act[grp] || (only_fresh && !s.take[grp])) return;
+    bool conv;
+    const uint64_t donemask = bps_done_mask(a, s, grp, lane, conv);
+    if (!donemask) return;
+    const bool done = (donemask >> lane) & 1ull;
+    const BpsGroup G = bps_group(g, a, grp);
+    const uint32_t n = g.n, Wn = (n + 63) / 64;
+    const uint64_t myi = done ? s.myi[grp * 64 + lane] : 0;
+    const bool fresh = (s.fresh[grp] >> lane) & 1ull;
+    uint64_t rany = 0;
+    for (uint32_t w = part * BPS_WAVES + wv; w < Wn; w += parts * BPS_WAVES) {
+        if (!done) continue;
+        const uint64_t d = G.dw[(size_t)w * 64 + lane];
+        if (a.source != SRC_SYNDROMES) {
+            const uint64_t e = G.ew[(size_t)w * 64 + lane];
+            rany |= e ^ d;
+            if (a.corr_out) a.corr_out[myi * Wn + w] = a.xor_input ? d ^ e : d;
+        } else if (a.corr_out) a.corr_out[myi * Wn + w] = d;
+    }
+    if (a.test == TEST_RESIDUAL && rany) atomicOr(&s.flags[grp * 64 + lane], 1u);
+    if (a.post_out && done)
+        for (uint32_t b = part * BPS_WAVES + wv; b < n; b += parts * BPS_WAVES) {      // BpState::decode posterior, :100-106
+            double l = a.prior;
+            if (!fresh)
+                for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) l += G.chkm[(size_t)g.t_edge[k] * 64 + lane];
+            a.post_out[myi * n + b] = l;
+        }
+}
+
+// one wave per group: counters and per-shot outputs of the slots that stop, slots freed; count_alive: add the
+// slots still active to *s.alive (the host's loop condition)
+__global__ __launch_bounds__(64) void bps_ctl_harvest(BpArgs a, BpsState s, uint32_t g0, int only_fresh, unsigned long long *alive)
+{
+    const size_t grp = g0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    uint64_t act = s.act[grp];
+    if (act && !(only_fresh && !s.take[grp])) {
+        bool conv;
+        const uint64_t donemask = bps_done_mask(a, s, grp, lane, conv);
+        const bool done = (donemask >> lane) & 1ull;
+        const bool det = !conv;
+        const bool fail = a.test == TEST_RESIDUAL && s.flags[grp * 64 + lane] != 0;
+        const uint32_t iter = s.iter[grp * 64 + lane];
+        if (done) {
+            const uint64_t myi = s.myi[grp * 64 + lane];
+            if (a.iters_out) a.iters_out[myi] = iter;
+            if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
+        }
+        const uint64_t c_shots = __builtin_popcountll(donemask), c_fail = __builtin_popcountll(__ballot(done && fail)),
+                       c_det = __builtin_popcountll(__ballot(done && det)), c_work = wave_sum64(done ? iter : 0);
+        if (lane == 0 && donemask && a.counters) {
+            atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+            if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+            if (c_det) {
+                atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+                atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_det);
+            }
+            if (c_fail > c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
+            if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
+        }
+        act &= ~donemask;
+        if (lane == 0) s.act[grp] = act;
+    }
+    if (alive && lane == 0 && act) atomicAdd(alive, (unsigned long long)__builtin_popcountll(act));
+}
+
+// (group, part): update_checks
+template <int DC>
+__device__ inline void bps_checks_body(const DeviceGraph &g, const BpArgs &a, const BpsState &s, size_t grp, uint32_t part, uint32_t parts)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t actmask = s.act[grp];
+    if (!actmask) return;
+    const BpsGroup G = bps_group(g, a, grp);
+    const bool active = (actmask >> lane) & 1ull, fresh = (s.fresh[grp] >> lane) & 1ull;
+    const double prior = a.prior;
+    const uint32_t m = g.m, first = part * BPS_WAVES + wv, step = parts * BPS_WAVES;
+    if constexpr (DC > 0) {
+        double xn[DC];
+        if (first < m) {
+#pragma unroll
+            for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : G.bitsm[((size_t)first * DC + j) * 64 + lane];
+        }
+        for (uint32_t c = first; c < m; c += step) {
+            const size_t e0 = (size_t)c * DC;
+            const bool sbit = (G.ssl[c] >> lane) & 1ull;
+            double x[DC];
+#pragma unroll
+            for (int j = 0; j < DC; j++) x[j] = xn[j];
+            if (c + step < m) {
+#pragma unroll
+                for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : G.bitsm[((size_t)(c + step) * DC + j) * 64 + lane];
+            }
+            double out[DC];
+            bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
+#pragma unroll
+            for (int j = 0; j < DC; j++)
+                if (active) G.chkm[(e0 + j) * 64 + lane] = out[j];
+        }
+    } else {
+        for (uint32_t c = first; c < m; c += step) {
+            const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+            const bool sbit = (G.ssl[c] >> lane) & 1ull;
+            double prod = 1.0;
+            for (uint32_t j = 0; j < dc; j++) {
+                const double x = fresh ? prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
+                prod *= bp_tanh_half(x);
+            }
+            for (uint32_t j = 0; j < dc; j++) {
+                const double x = fresh ? prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
+                double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, bp_tanh_half(x)));
+                if (sbit) v *= -1.0;
+                if (active) G.chkm[(size_t)(e0 + j) * 64 + lane] = v;
+            }
+        }
+    }
+}
+
+// (group, part): update_bits + hard decisions
+template <int DV>
+__device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, const BpsState &s, size_t grp, uint32_t part, uint32_t parts)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t actmask = s.act[grp];
+    if (!actmask) return;
+    const BpsGroup G = bps_group(g, a, grp);
+    const bool active = (actmask >> lane) & 1ull;
+    const uint32_t Wn = (g.n + 63) / 64;
+    for (uint32_t chunk = part * BPS_WAVES + wv; chunk < Wn; chunk += parts * BPS_WAVES)
+        bp_bits_chunk<DV>(g, chunk, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
+}
+
+// One half-step of the streamed form: update_checks on the groups [gc0, gc0 + gcn) and update_bits on the
+// groups [gb0, gb0 + gbn), blocks of the two roles interleaved so that every CU holds both: the check update
+// is bound by f64 issue, the bit update by HBM, and two group sets half an iteration apart keep both busy.
+template <int DC, int DV>
+__global__ __launch_bounds__(BPS_THREADS, 4) void bps_iterate(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t gc0,
+                                                              uint32_t gcn, uint32_t gb0, uint32_t gbn)
+{
+    const uint32_t nc = gcn * parts, nb = gbn * parts, mn = nc < nb ? nc : nb;
+    bool checks;
+    uint32_t idx;
+    if (blockIdx.x < 2 * mn) {
+        checks = !(blockIdx.x & 1);
+        idx = blockIdx.x >> 1;
+    } else {
+        checks = nc > nb;
+        idx = blockIdx.x - mn;
+    }
+    if (checks) bps_checks_body<DC>(g, a, s, gc0 + idx / parts, idx % parts, parts);
+    else bps_bits_body<DV>(g, a, s, gb0 + idx / parts, idx % parts, parts);
+}
+
+// one wave per group: the iteration is over
+__global__ __launch_bounds__(64) void bps_ctl_advance(BpsState s, uint32_t g0)
+{
+    const size_t grp = g0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t act = s.act[grp];
+    if ((act >> lane) & 1ull) s.iter[grp * 64 + lane] += 1;
+    if (lane == 0) {
+        s.fresh[grp] &= ~act;
+        s.mism[grp] = 0;
     }
 }
 
@@ -1212,6 +1569,94 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 {
     if (!a.n_shots || !groups) return hipSuccess;
     hipLaunchKernelGGL(bp_kernel_for(dc, dv), dim3(groups), dim3(64 * waves), 0, st, g, a);
+    return hipGetLastError();
+}
+
+size_t bp_stream_state_bytes(uint32_t groups) { return (size_t)groups * (5 * 8 + 64 * (4 + 8 + 4)) + 64; }
+
+// Runs the streamed BP to completion on `st`.  `state` = bp_stream_state_bytes(groups) bytes of device memory.
+hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
+                         uint64_t *rounds_out)
+{
+    if (!a.n_shots || !groups) return hipSuccess;
+    hipError_t e = hipMemsetAsync(state, 0, bp_stream_state_bytes(groups), st);
+    if (e != hipSuccess) return e;
+    BpsState s;
+    char *p = (char *)state;
+    s.alive = (unsigned long long *)p; p += 64;
+    s.act = (uint64_t *)p; p += (size_t)groups * 8;
+    s.fresh = (uint64_t *)p; p += (size_t)groups * 8;
+    s.take = (uint64_t *)p; p += (size_t)groups * 8;
+    s.mism = (uint64_t *)p; p += (size_t)groups * 8;
+    s.myi = (uint64_t *)p; p += (size_t)groups * 64 * 8;
+    s.iter = (uint32_t *)p; p += (size_t)groups * 64 * 4;
+    s.flags = (uint32_t *)p;
+    // parts: enough blocks to fill the chip a few times over, no more than the work items of the smallest phase
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t Wn = (g.n + 63) / 64;
+    uint32_t parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / groups);
+    parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+    const dim3 blk(BPS_THREADS), one(64);
+    // two sets of groups half an iteration apart (see bps_iterate); a single group runs alone
+    // Measured at C5: no gain from the skew (a check-update wave keeps its SIMD only 22 % busy, so the check update
+    // needs all four wave slots of a SIMD to itself); one set by default, LDPC_HIP_BP_STREAM_SKEW=1 for experiments
+    const bool skew = std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
+    const uint32_t set0[2] = {0, skew ? (groups + 1) / 2 : groups}, setn[2] = {skew ? (groups + 1) / 2 : groups, skew ? groups / 2 : 0};
+    unsigned long long alive[2] = {0, 0};
+    bool wants_checks[2] = {true, true};
+    // stop test, harvest, refill, set-up, stop test and harvest of the new shots (a zero syndrome stops at once)
+    auto control = [&](int t) -> hipError_t {
+        const dim3 grid(setn[t] * parts), ctl(setn[t]);
+        const uint32_t g0 = set0[t];
+        hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 0);
+        hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 0);
+        hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 0, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(bps_ctl_refill, ctl, one, 0, st, a, s, g0);
+        hipLaunchKernelGGL(bps_setup_words, grid, blk, 0, st, g, a, s, parts, g0);
+        hipLaunchKernelGGL(bps_setup_synd, grid, blk, 0, st, g, a, s, parts, g0);
+        hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 1);
+        hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 1);
+        hipError_t err = hipMemsetAsync(s.alive + t, 0, 8, st);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 1, s.alive + t);
+        if ((err = hipMemcpyAsync(&alive[t], s.alive + t, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
+        return hipStreamSynchronize(st);
+    };
+    auto iterate = [&](int c, int b) {
+        const uint32_t gc0 = c >= 0 ? set0[c] : 0, gcn = c >= 0 ? setn[c] : 0, gb0 = b >= 0 ? set0[b] : 0, gbn = b >= 0 ? setn[b] : 0;
+        const dim3 grid((gcn + gbn) * parts);
+        if (dc == 6 && dv == 3) hipLaunchKernelGGL((bps_iterate<6, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
+        else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bps_iterate<4, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
+        else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
+        else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
+    };
+    for (int t = 0; t < 2; t++)
+        if (setn[t] && (e = control(t)) != hipSuccess) return e;
+    const uint64_t max_rounds = 2 * (((a.n_shots + 64ull * groups - 1) / (64ull * groups) + 1) * ((uint64_t)a.max_iter + 2) + 2);
+    uint64_t rounds = 0;
+    if (alive[0] && alive[1]) {   // skew the sets: set 0 starts half an iteration early
+        iterate(0, -1);
+        wants_checks[0] = false;
+    }
+    while (alive[0] || alive[1]) {
+        if (++rounds > max_rounds) return hipErrorLaunchFailure;   // cannot happen: every round stops or advances every active slot
+        int c = -1, b = -1;
+        for (int t = 1; t >= 0; t--)
+            if (alive[t]) {
+                if (wants_checks[t]) c = t;
+                else b = t;
+            }
+        iterate(c, b);
+        if (c >= 0) wants_checks[c] = false;
+        if (b >= 0) {
+            hipLaunchKernelGGL(bps_ctl_advance, dim3(setn[b]), one, 0, st, s, set0[b]);
+            if ((e = control(b)) != hipSuccess) return e;
+            wants_checks[b] = true;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (rounds_out) *rounds_out = rounds;
     return hipGetLastError();
 }
 

@@ -69,6 +69,15 @@ struct BpArgs {
     GapTable gap;
 };
 
+// slot state of the streamed BP form (bp_stream_run), device memory: per group u64 masks over its 64 slots,
+// per slot the shot index, iteration count and residual flag
+struct BpsState {
+    unsigned long long *alive;          // [2] per group set: active slots after the round's harvest (host loop condition)
+    uint64_t *act, *fresh, *take, *mism; // [groups]
+    uint64_t *myi;                      // [groups][64]
+    uint32_t *iter, *flags;             // [groups][64]
+};
+
 // 2-hop neighbourhood table of the flip decoder: for every bit b, K slots of
 // (bit, its checks): slot 0 is b itself, the others are the bits that share a
 // check with b.  One flip touches exactly these bits, so one contiguous
@@ -101,6 +110,9 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);
+size_t bp_stream_state_bytes(uint32_t groups);
+hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
+                         uint64_t *rounds_out);
 hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
 
 }  // namespace ldpc

@@ -1,0 +1,95 @@
+"""The streamed BP form (one grid-wide kernel per phase; used when a 64-shot group's messages are so large that
+memory allows few groups, C5) against the persistent kernel and the oracle.  Both forms run the same arithmetic
+in the same order, so their outputs are compared bit for bit; LDPC_HIP_BP_PATH forces the form on small codes."""
+import numpy as np
+import pytest
+
+from ldpc_amd import CNT_FAILURES, CNT_SHOTS, CNT_WORK, BpDecoder, LinearCode, nwords
+from oracle import oracle as orc
+from tests.gpu_util import dev_f64, dev_u32, dev_u64, dev_u8, host_u32, host_u64, oracle_code, random_sparse_rows, to_dev_u64
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(monkeypatch, fn):
+    out = {}
+    for path in ("persistent", "stream"):
+        monkeypatch.setenv("LDPC_HIP_BP_PATH", path)
+        out[path] = fn()
+    monkeypatch.delenv("LDPC_HIP_BP_PATH")
+    return out["persistent"], out["stream"]
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("n,m,dv,dc,p,shots,max_iter", [(1200, 900, 3, 4, 0.02, 300, 100), (1200, 900, 3, 4, 0.07, 200, 15),
+                                                        (10000, 5000, 3, 6, 0.02, 130, 100), (600, 300, 3, 6, 0.04, 1000, 40)])
+def test_stream_correction_for_equals_persistent(monkeypatch, n, m, dv, dc, p, shots, max_iter):
+    code = LinearCode.random_regular_code(n, m, dv, dc, seed=3)
+    oc = oracle_code(code)
+    syn = np.zeros((shots, nwords(m)), dtype=np.uint64)
+    for i in range(shots):
+        syn[i] = oc.syndrome_words(orc.sample_bsc_words(11, i, p, n))
+
+    def run():
+        dec = BpDecoder(code, p, max_iter)
+        dc_, di, dp = dev_u64((shots, nwords(n))), dev_u32((shots,)), dev_f64((shots, n))
+        dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di, dp)
+        return host_u64(dc_), host_u32(di), dp.cpu().numpy()
+
+    pers, strm = _both(monkeypatch, run)
+    assert _same(pers, strm)
+    # and the oracle on a sample
+    for i in range(0, shots, 37):
+        c, it, _ = oc.bp_correction_for(p, max_iter, syn[i])
+        if (strm[0][i] == c).all():
+            assert strm[1][i] == it
+
+
+def test_stream_irregular_codes_and_decode(monkeypatch):
+    rng = np.random.default_rng(9)
+    for (n, m, maxdeg) in [(1, 0, 1), (7, 3, 4), (65, 40, 6), (130, 90, 12), (300, 200, 5)]:
+        rows = random_sparse_rows(rng, n, m, maxdeg)
+        code = LinearCode.from_parity_check_matrix(n, rows)
+        shots = 150
+        words = np.stack([orc.sample_bsc_words(5, i, 0.08, n) for i in range(shots)]).reshape(shots, max(nwords(n), 1))
+
+        def run():
+            dec = BpDecoder(code, 0.08, 12)
+            do = dev_u64(words.shape)
+            dec.decode_batch(shots, to_dev_u64(words), do)
+            return (host_u64(do),)
+
+        pers, strm = _both(monkeypatch, run)
+        assert _same(pers, strm), (n, m)
+
+
+def test_stream_mc_counters_and_flags(monkeypatch):
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+
+    def run():
+        dec = BpDecoder(code, 0.06, 25)
+        flags = dev_u8((5000,))
+        cnt = dec.mc_run(0.06, 2024, 100, 5000, flags)
+        return cnt, flags.cpu().numpy()
+
+    pers, strm = _both(monkeypatch, run)
+    assert _same(pers, strm)
+    assert strm[0][CNT_SHOTS] == 5000 and int(strm[1].sum()) == strm[0][CNT_FAILURES]
+    ref = oracle_code(code).mc_bp(0.06, 25, 2024, 100, 5000, nthreads=8)
+    assert abs(int(strm[0][CNT_FAILURES]) - int(ref[CNT_FAILURES])) <= 2
+    assert abs(int(strm[0][CNT_WORK]) - int(ref[CNT_WORK])) <= 20
+
+
+def test_stream_split_invariance_and_empty(monkeypatch):
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "stream")
+    code = LinearCode.random_regular_code(96, 72, 3, 4, seed=2)
+    dec = BpDecoder(code, 0.05, 30)
+    total = dec.mc_run(0.05, 7, 0, 9000)
+    a = dec.mc_run(0.05, 7, 0, 4321)
+    b = dec.mc_run(0.05, 7, 4321, 9000 - 4321)
+    assert ((a + b) == total).all()
+    assert dec.mc_run(0.05, 7, 0, 0)[CNT_SHOTS] == 0
+    assert dec.mc_run(0.05, 7, 0, 1)[CNT_SHOTS] == 1
