@@ -255,7 +255,7 @@ bool build_nb_table(const LinearCode &c, std::vector<uint32_t> &out, uint32_t &k
     const SparseBinMat &h = c.h, &t = c.ht;
     const uint32_t n = h.ncols;
     const uint32_t max_dv = t.max_row_len();
-    if (max_dv > 7) return false;
+    if (max_dv > 7 || h.nrows() >= (1u << 19) - 64) return false;   // packed check format: word offsets below 2^16
     dvp = max_dv <= 3 ? 3 : 7;
     std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
     uint32_t kmax = 1;
@@ -276,7 +276,8 @@ bool build_nb_table(const LinearCode &c, std::vector<uint32_t> &out, uint32_t &k
     auto put = [&](uint32_t b, size_t slot, uint32_t bit) {
         uint32_t *r = &out[((size_t)b * K + slot) * rec];
         r[0] = bit;
-        for (uint32_t k = t.ptr[bit]; k < t.ptr[bit + 1]; k++) r[1 + (k - t.ptr[bit])] = t.idx[k];
+        // a check c is stored as (byte offset of its 32-bit syndrome word) << 16 | bit in that word
+        for (uint32_t k = t.ptr[bit]; k < t.ptr[bit + 1]; k++) r[1 + (k - t.ptr[bit])] = ((t.idx[k] >> 5) * 4u) << 16 | (t.idx[k] & 31u);
     };
     for (uint32_t b = 0; b < n; b++) {
         size_t slot = 0;

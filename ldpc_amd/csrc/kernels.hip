@@ -308,13 +308,17 @@ template <int DVP> struct alignas(16) NbRec {
     uint32_t chk[DVP];
 };
 
-template <int DVP, bool REG> __device__ inline bool rec_flippable(const NbRec<DVP> &r, const uint32_t *S32)
+// chk fields of a record are packed: (byte offset of the check's 32-bit syndrome word) << 16 | bit in that word
+__device__ inline uint32_t *chk_word(uint32_t *S32, uint32_t chk) { return (uint32_t *)((char *)S32 + (chk >> 16)); }
+__device__ inline uint32_t chk_mask(uint32_t chk) { return 1u << (chk & 31); }
+
+template <int DVP, bool REG> __device__ inline bool rec_flippable(const NbRec<DVP> &r, uint32_t *S32)
 {
     // all S reads are issued back to back (one LDS wait), then reduced.  REG: every bit has
     // exactly DVP checks, no sentinel tests.
     uint32_t word[DVP];
 #pragma unroll
-    for (int k = 0; k < DVP; k++) word[k] = S32[(REG || r.chk[k] != NONE) ? (r.chk[k] >> 5) : 0];
+    for (int k = 0; k < DVP; k++) word[k] = *chk_word(S32, (REG || r.chk[k] != NONE) ? r.chk[k] : 0u);
     uint32_t deg = 0, unsat = 0;
 #pragma unroll
     for (int k = 0; k < DVP; k++) {
@@ -364,13 +368,15 @@ __device__ inline uint32_t row_min_u32(uint32_t v)
 }
 
 // ONE: K == G, every row is exactly one round of the group (kshift becomes a constant, the round loop unrolls away)
-template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
+// SMALL: one window of G summary words covers the whole flippable mask (n <= 1024 G): no scan cursor
+template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ __launch_bounds__(64) void flip2_kernel(DeviceGraph g, NbTable nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
     constexpr uint32_t SPW = 64 / G;                 // shots per wave
     const uint32_t lane = threadIdx.x, grp = lane / G, gl = lane % G;
     const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    const uint32_t WS = (Wn + 63) / 64;              // summary words: bit w of FS set if F[w] may be non-zero
+    const uint32_t WS = (2 * Wn + 63) / 64;          // u64 words of the summary FS (one bit per u32 word of F)
+    const uint32_t WS32 = (2 * Wn + 31) / 32;        // FS as u32 words: bit w set if the u32 word w of F may be non-zero
     const uint32_t per_shot = Wm + Wn + WS;          // LDS words per shot: S, F, FS (O lives in HBM)
     uint32_t *q = (uint32_t *)lds;
     uint32_t *list = (uint32_t *)(lds + 33);         // error positions of the shot being set up
@@ -428,7 +434,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                     const NbRec<DVP> r = nb[(size_t)list[t] << kshift];
 #pragma unroll
                     for (int k = 0; k < DVP; k++)
-                        if (r.chk[k] != NONE) atomicXor(&S32[r.chk[k] >> 5], 1u << (r.chk[k] & 31));
+                        if (r.chk[k] != NONE) atomicXor(chk_word(S32, r.chk[k]), chk_mask(r.chk[k]));
                 }
                 wave_order();
                 // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
@@ -436,7 +442,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                     const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
                     if (r.bit != NONE && rec_flippable<DVP, REG>(r, S32)) {
                                     atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
-                                    atomicOr(&FS32[r.bit >> 11], 1u << ((r.bit >> 6) & 31));
+                                    atomicOr(&FS32[r.bit >> 10], 1u << ((r.bit >> 5) & 31));
                                 }
                 }
             } else {
@@ -464,14 +470,14 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                                 const NbRec<DVP> r = nb[(size_t)list[t] << kshift];
 #pragma unroll
                                 for (int k = 0; k < DVP; k++)
-                                    if (r.chk[k] != NONE) atomicXor(&S32[r.chk[k] >> 5], 1u << (r.chk[k] & 31));
+                                    if (r.chk[k] != NONE) atomicXor(chk_word(S32, r.chk[k]), chk_mask(r.chk[k]));
                             }
                         } else {
                             for (uint32_t t = lane; t < (cnt << kshift); t += 64) {
                                 const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
                                 if (r.bit != NONE && rec_flippable<DVP, REG>(r, S32)) {
                                     atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
-                                    atomicOr(&FS32[r.bit >> 11], 1u << ((r.bit >> 6) & 31));
+                                    atomicOr(&FS32[r.bit >> 10], 1u << ((r.bit >> 5) & 31));
                                 }
                             }
                         }
@@ -487,52 +493,45 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
         {
             uint64_t *S = state + (size_t)grp * per_shot, *F = S + Wm, *FS = F + Wn;
             uint32_t *S32 = (uint32_t *)S, *F32 = (uint32_t *)F, *FS32 = (uint32_t *)FS;
-            // flip log of this group's shot: G flips are gathered in registers (lane t keeps flip t mod G),
-            // then written as one coalesced row; at most m flips per shot (each lowers the syndrome weight)
+            // flip log of this group's shot, one entry per flip; at most m flips per shot (each lowers the
+            // syndrome weight)
             uint32_t *flog = a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;
-            uint32_t mylog = 0;
             bool active = grp < nvalid;
-            uint32_t curS = 0, nfl = 0;   // invariant: no flippable bit in F words below 64*curS
+            uint32_t curS = 0, nfl = 0;   // invariant: no flippable bit in F words below 32*curS
             const uint32_t max_flips = a.max_flips;
-            const bool big = WS > G;      // otherwise one window covers the whole summary and curS stays 0
             while (__ballot(active)) {
                 // lowest flippable bit of the shot, two levels: the summary FS names the first F word that may
                 // be non-zero (each lane looks at one summary word, the group takes the minimum), then that
                 // F word gives the bit.  A summary bit can be stale (set, word empty): it is cleared and the
                 // iteration does nothing else.
-                const uint32_t sw = curS + gl;
-                const uint64_t fs = (active && sw < WS) ? FS[sw] : 0;
-                uint32_t candw = fs ? (sw << 6) + (uint32_t)__builtin_ctzll(fs) : NONE;
+                const uint32_t sw = SMALL ? gl : curS + gl;
+                const uint32_t fs = (active && sw < WS32) ? FS32[sw] : 0;
+                uint32_t candw = fs ? (sw << 5) + (uint32_t)__builtin_ctz(fs) : NONE;
                 candw = group_min_u32<G>(candw);
                 const bool havew = active && candw != NONE;
-                if (active && !havew) {
-                    curS += G;
-                    if (curS >= WS) active = false;                     // flip.rs:27 find_flippable == None
+                if (active && !havew) {                                 // flip.rs:27 find_flippable == None
+                    if (SMALL) active = false;
+                    else {
+                        curS += G;
+                        if (curS >= WS32) active = false;
+                    }
                 }
-                const uint64_t x = havew ? F[candw] : 0;
+                const uint32_t x = havew ? F32[candw] : 0;
                 const bool found = havew && x != 0;
                 if (havew && !found && gl == 0) atomicAnd(&FS32[candw >> 5], ~(1u << (candw & 31)));
-                const uint32_t b = found ? (candw << 6) + (uint32_t)__builtin_ctzll(x) : 0u;
+                const uint32_t b = found ? (candw << 5) + (uint32_t)__builtin_ctz(x) : 0u;
                 uint32_t minset = NONE;
-                NbRec<DVP> rec_next;
-                rec_next.bit = NONE;
-#pragma unroll
-                for (int k = 0; k < DVP; k++) rec_next.chk[k] = NONE;
-                if (found) rec_next = nb[((size_t)b << kshift) + gl];
+                // the row of b (row 0 for a group with nothing to flip: a harmless read, no divergence)
+                NbRec<DVP> rec_next = nb[((size_t)b << kshift) + gl];
                 for (uint32_t r = 0; r < K; r += G) {
                     const NbRec<DVP> rec = rec_next;
-                    if (r + G < K && found) rec_next = nb[((size_t)b << kshift) + r + G + gl];   // next round's slots in flight
+                    if (r + G < K) rec_next = nb[((size_t)b << kshift) + r + G + gl];   // next round's slots in flight
                     if (r == 0) {
                         // slot 0 (lane 0 of the group) is b itself: syndrome ^= H e_b (flip.rs:28-29)
                         if (found && gl == 0) {   // one lane per shot: the atomics of idle lanes would only collide
 #pragma unroll
-                            for (int k = 0; k < DVP; k++) {
-                                if (REG) atomicXor(&S32[rec.chk[k] >> 5], 1u << (rec.chk[k] & 31));
-                                else {
-                                    const bool v = rec.chk[k] != NONE;
-                                    atomicXor(&S32[v ? (rec.chk[k] >> 5) : 0], v ? (1u << (rec.chk[k] & 31)) : 0u);
-                                }
-                            }
+                            for (int k = 0; k < DVP; k++)
+                                if (REG || rec.chk[k] != NONE) atomicXor(chk_word(S32, rec.chk[k]), chk_mask(rec.chk[k]));
                             // b was the only flippable bit of its word: the word empties (a neighbour that
                             // becomes flippable in it sets the summary bit again below)
                             if ((x & (x - 1)) == 0) atomicAnd(&FS32[candw >> 5], ~(1u << (candw & 31)));
@@ -540,26 +539,26 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                         wave_order();
                     }
                     // every slot re-evaluates its bit against the new syndrome and fixes its F bit
-                    const bool have = rec.bit != NONE;
+                    const bool have = found && rec.bit != NONE;
                     const uint32_t fword = F32[have ? (rec.bit >> 5) : 0];
                     const bool fl = have && rec_flippable<DVP, REG>(rec, S32);
                     const bool old = (fword >> (rec.bit & 31)) & 1u;
                     if (have && fl != old) {
                         atomicXor(&F32[rec.bit >> 5], 1u << (rec.bit & 31));
-                        if (fl) atomicOr(&FS32[rec.bit >> 11], 1u << ((rec.bit >> 6) & 31));
+                        if (fl) atomicOr(&FS32[rec.bit >> 10], 1u << ((rec.bit >> 5) & 31));
                     }
-                    if (big && fl) minset = rec.bit < minset ? rec.bit : minset;
+                    if (!SMALL && fl) minset = rec.bit < minset ? rec.bit : minset;
                 }
                 // output ^= e_b (flip.rs:30) is deferred: log the flip
                 if (found) {
-                    if ((nfl & (G - 1)) == gl) mylog = b;
+                    if (nfl >= a.flip_log_cap) active = false;   // cannot happen (<= m flips); never write past the log
+                    else if (gl == 0) flog[nfl] = b;
                     nfl++;
-                    if ((nfl & (G - 1)) == 0) flog[nfl - G + gl] = mylog;
                 }
-                if (big) {   // more summary words than lanes: keep the scan cursor at the lowest possible word
+                if (!SMALL) {   // more summary words than lanes: keep the scan cursor at the lowest possible word
                     minset = group_min_u32<G>(minset);
                     if (found) {
-                        const uint32_t bs = b >> 12, ms = minset == NONE ? NONE : minset >> 12;
+                        const uint32_t bs = b >> 10, ms = minset == NONE ? NONE : minset >> 10;
                         curS = ms < bs ? ms : bs;
                     }
                 }
@@ -567,8 +566,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                 if (DIAG && active) c_iters++;                  // profiling aid: loop iterations incl. empty ones
                 if (DIAG && nfl >= max_flips) active = false;   // profiling aid only
             }
-            if (gl < (nfl & (G - 1))) flog[(nfl & ~(uint32_t)(G - 1)) + gl] = mylog;   // last, partial row
-            wave_sync();   // log rows are in memory
+            wave_sync();   // log entries are in memory
             // ---------------------------------------------------------------- failure test + outputs
             for (uint32_t j = 0; j < nvalid; j++) {
                 uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Wm;   // F is dead: rebuild the word there
@@ -576,7 +574,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE> __global__ __launch_bou
                 const uint64_t *Ej = err_words(j);
                 const uint32_t *lj = a.flip_log + ((size_t)blockIdx.x * SPW + j) * a.flip_log_cap;
                 const uint64_t i = base + j;
-                const uint32_t nf = __shfl(nfl, j * G, 64);
+                const uint32_t nfj = __shfl(nfl, j * G, 64), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
                 // device-scope loads: both were written by this wave, possibly through another lane
                 for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&Ej[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wave_order();
@@ -1492,7 +1490,7 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
 size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot)
 {
     size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    return (FLIP2_HDR + (64 / lanes_per_shot) * (Wm + Wn + (Wn + 63) / 64)) * 8;
+    return (FLIP2_HDR + (64 / lanes_per_shot) * (Wm + Wn + (2 * Wn + 63) / 64)) * 8;
 }
 
 uint32_t flip2_lanes_per_shot(const DeviceGraph &g)
@@ -1515,15 +1513,21 @@ static void launch_flip2_t(const DeviceGraph &g, const NbTable &nb, const FlipAr
 {
     const bool diag = a.max_flips != 0xFFFFFFFFu;
     const bool one = !diag && (1u << nb.kshift) == (uint32_t)G;
+    const bool small = one && (2 * ((g.n + 63) / 64) + 31) / 32 <= (uint32_t)G;
+#define LDPC_FLIP2(REG_, DIAG_, ONE_, SMALL_) \
+    hipLaunchKernelGGL((flip2_kernel<DVP, G, REG_, DIAG_, ONE_, SMALL_>), dim3(grid), dim3(64), lds, st, g, nb, a)
     if (nb.regular) {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else if (one) hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<DVP, G, true, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (diag) LDPC_FLIP2(true, true, false, false);
+        else if (small) LDPC_FLIP2(true, false, true, true);
+        else if (one) LDPC_FLIP2(true, false, true, false);
+        else LDPC_FLIP2(true, false, false, false);
     } else {
-        if (diag) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, true, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else if (one) hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false, true>), dim3(grid), dim3(64), lds, st, g, nb, a);
-        else hipLaunchKernelGGL((flip2_kernel<DVP, G, false, false, false>), dim3(grid), dim3(64), lds, st, g, nb, a);
+        if (diag) LDPC_FLIP2(false, true, false, false);
+        else if (small) LDPC_FLIP2(false, false, true, true);
+        else if (one) LDPC_FLIP2(false, false, true, false);
+        else LDPC_FLIP2(false, false, false, false);
     }
+#undef LDPC_FLIP2
 }
 
 hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st)
