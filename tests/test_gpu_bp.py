@@ -133,3 +133,33 @@ def test_bp_refill_and_split_invariance():
     ref = oc.mc_bp(0.05, 30, 7, 0, 20000, nthreads=8)
     assert abs(int(total[CNT_FAILURES]) - int(ref[CNT_FAILURES])) <= 2
     assert abs(int(total[CNT_WORK]) - int(ref[CNT_WORK])) <= 20
+
+
+def test_bp_full_size_properties():
+    # C2 shape, 2^15 shots, properties that need no oracle: where BP stops before the cap the correction
+    # reproduces the syndrome (H c = s, belief_propagation.rs:26-27); decode(e) = e ^ correction_for(H e);
+    # Monte-Carlo failures = shots whose correction differs from the error; counters add over a split range
+    n, m, shots, p, cap = 10000, 5000, 1 << 15, 0.03, 30
+    code = LinearCode.random_regular_code(n, m, 3, 6, seed=1)
+    dec = BpDecoder(code, p, cap)
+    from ldpc_amd import BinarySymmetricChannel
+    de, ds = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m)))
+    BinarySymmetricChannel(p).sample_batch(n, SEED, 0, shots, de)
+    code.syndrome_batch(shots, de, ds)
+    dc, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+    dec.correction_for_batch(shots, ds, dc, di)
+    chk = dev_u64((shots, nwords(m)))
+    code.syndrome_batch(shots, dc, chk)
+    stopped = di < cap
+    assert int(stopped.sum()) > shots * 0.99
+    assert bool((chk == ds)[stopped].all())
+    do = dev_u64((shots, nwords(n)))
+    dec.decode_batch(shots, de, do)
+    assert bool((do == (de ^ dc)).all())
+    flags = dev_u8((shots,))
+    cnt = dec.mc_run(p, SEED, 0, shots, flags)
+    assert int((do != 0).any(dim=1).sum()) == cnt[CNT_FAILURES] == int(flags.sum())
+    assert int(di.sum()) == cnt[CNT_WORK] and int((~stopped).sum()) >= cnt[CNT_CAPPED]
+    a = dec.mc_run(p, SEED, 0, 12345)
+    b = dec.mc_run(p, SEED, 12345, shots - 12345)
+    assert ((a + b) == cnt).all()
