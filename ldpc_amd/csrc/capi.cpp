@@ -239,9 +239,9 @@ int read_counters(DeviceBuffer &d, uint64_t *out)
 
 int zero_counters(DeviceBuffer &d)
 {
-    // LDPC_COUNTERS counters followed by one work-queue word (bp_kernel)
-    HIP_TRY(d.reserve(sizeof(unsigned long long) * (LDPC_COUNTERS + 1)));
-    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * (LDPC_COUNTERS + 1), g_stream));
+    // LDPC_COUNTERS counters followed by the work-queue word and the hand-off flag (bp_kernel)
+    HIP_TRY(d.reserve(sizeof(unsigned long long) * (LDPC_COUNTERS + 2)));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * (LDPC_COUNTERS + 2), g_stream));
     return LDPC_OK;
 }
 
@@ -463,8 +463,31 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         uint64_t rounds = 0;
         HIP_TRY(bp_stream_run(g, a, dec->stream_state.as<char>(), (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds));
         if (std::getenv("LDPC_HIP_DEBUG")) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu rounds\n", (unsigned long long)rounds);
-    } else
+    } else {
+        // tail hand-off (kernels.hpp, BpArgs::handoff_iter): shots still running 16 iterations after the queue
+        // has drained are finished by the streamed form, the whole chip on the few groups that hold them
+        uint32_t handoff = 16;
+        if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) handoff = (uint32_t)std::strtoul(e, nullptr, 10);   // 0 = off
+        if (handoff == 0 || r.test == TEST_LOGICAL || dec->max_iter <= handoff) handoff = 0xFFFFFFFFu;
+        a.handoff_iter = handoff;
+        if (handoff != 0xFFFFFFFFu) {
+            HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
+            HIP_TRY(hipMemsetAsync(dec->stream_state.p, 0, bp_stream_state_bytes((uint32_t)groups), g_stream));
+            a.handoff = bp_stream_state_at(dec->stream_state.p, (uint32_t)groups);
+            a.handoff_flag = dec->counters.as<unsigned long long>() + LDPC_COUNTERS + 1;
+        }
         HIP_TRY(launch_bp(g, a, (uint32_t)groups, waves, dec->reg_dc, dec->reg_dv, g_stream));
+        if (handoff != 0xFFFFFFFFu) {
+            unsigned long long flag = 0;
+            HIP_TRY(hipMemcpyAsync(&flag, a.handoff_flag, 8, hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            if (flag) {
+                uint64_t rounds = 0;
+                HIP_TRY(bp_stream_run(g, a, dec->stream_state.p, (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds, true));
+                if (std::getenv("LDPC_HIP_DEBUG")) std::fprintf(stderr, "[ldpc_hip] bp tail hand-off: %llu streamed rounds\n", (unsigned long long)rounds);
+            }
+        }
+    }
     if (timer) timer->stop_and_store();
     if (counters_out) return read_counters(dec->counters, counters_out);
     HIP_TRY(hipStreamSynchronize(g_stream));

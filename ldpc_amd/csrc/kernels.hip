@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "bp_math.hpp"
 #include "kernels.hpp"
@@ -996,6 +997,20 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             if (!drained) continue;     // refill before spending an iteration
             if (!__ballot(active)) break;
         }
+        // tail hand-off: nothing left to refill with and only long-running shots remain in this group
+        if (drained && a.handoff_iter != 0xFFFFFFFFu && __ballot(active) && !__ballot(active && iter < a.handoff_iter)) {
+            if (wv == 0) {
+                const uint64_t am = __ballot(active), fm = __ballot(active && fresh);
+                a.handoff.iter[grp * 64 + lane] = iter;
+                a.handoff.myi[grp * 64 + lane] = myi;
+                if (lane == 0) {
+                    a.handoff.act[grp] = am;
+                    a.handoff.fresh[grp] = fm;
+                    atomicExch(a.handoff_flag, 1ull);
+                }
+            }
+            break;
+        }
 
         // ---- one BP iteration on the active slots (update_once, :133-140) -----
         // update_checks (:150-166): the waves take the checks round-robin
@@ -1116,6 +1131,8 @@ __device__ inline BpsGroup bps_group(const DeviceGraph &g, const BpArgs &a, size
     return r;
 }
 
+__device__ inline size_t bps_grp(const BpsState &s, uint32_t i) { return s.gmap ? s.gmap[i] : i; }
+
 // slots whose shot stops now: converged (stop test) or at the iteration cap (belief_propagation.rs:26-27)
 __device__ inline uint64_t bps_done_mask(const BpArgs &a, const BpsState &s, size_t grp, uint32_t lane, bool &conv)
 {
@@ -1127,7 +1144,7 @@ __device__ inline uint64_t bps_done_mask(const BpArgs &a, const BpsState &s, siz
 // one wave per group: hand idle slots their next shots
 __global__ __launch_bounds__(64) void bps_ctl_refill(BpArgs a, BpsState s, uint32_t g0)
 {
-    const size_t grp = g0 + blockIdx.x;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x);
     const uint32_t lane = threadIdx.x;
     const uint64_t act = s.act[grp], idle = ~act;
     uint64_t first = a.n_shots;
@@ -1157,7 +1174,7 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_words(DeviceGraph g, Bp
 {
     __shared__ uint32_t q[65];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t grp = g0 + blockIdx.x / parts;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x / parts);
     const uint32_t part = blockIdx.x % parts;
     const uint64_t takemask = s.take[grp];
     if (!takemask) return;
@@ -1223,7 +1240,7 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_words(DeviceGraph g, Bp
 // (group, part): syndromes of the taken slots from the bit-sliced error rows, thread per check
 __global__ __launch_bounds__(BPS_THREADS) void bps_setup_synd(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0)
 {
-    const size_t grp = g0 + blockIdx.x / parts;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x / parts);
     const uint32_t part = blockIdx.x % parts;
     const uint64_t takemask = s.take[grp];
     if (!takemask || a.source == SRC_SYNDROMES) return;
@@ -1238,7 +1255,7 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_synd(DeviceGraph g, BpA
 // (group, part): stop test, bit-sliced; only_fresh: groups that took no shot this round are skipped
 __global__ __launch_bounds__(BPS_THREADS) void bps_stop(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0, int only_fresh)
 {
-    const size_t grp = g0 + blockIdx.x / parts;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x / parts);
     const uint32_t part = blockIdx.x % parts;
     if (!s.act[grp] || (only_fresh && !s.take[grp])) return;
     const BpsGroup G = bps_group(g, a, grp);
@@ -1256,7 +1273,7 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_stop(DeviceGraph g, BpArgs a,
 __global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0, int only_fresh)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t grp = g0 + blockIdx.x / parts;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x / parts);
     const uint32_t part = blockIdx.x % parts;
     if (!s.act[grp] || (only_fresh && !s.take[grp])) return;
     bool conv;
@@ -1291,7 +1308,7 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, 
 // slots still active to *s.alive (the host's loop condition)
 __global__ __launch_bounds__(64) void bps_ctl_harvest(BpArgs a, BpsState s, uint32_t g0, int only_fresh, unsigned long long *alive)
 {
-    const size_t grp = g0 + blockIdx.x;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x);
     const uint32_t lane = threadIdx.x;
     uint64_t act = s.act[grp];
     if (act && !(only_fresh && !s.take[grp])) {
@@ -1407,14 +1424,14 @@ __global__ __launch_bounds__(BPS_THREADS, 4) void bps_iterate(DeviceGraph g, BpA
         checks = nc > nb;
         idx = blockIdx.x - mn;
     }
-    if (checks) bps_checks_body<DC>(g, a, s, gc0 + idx / parts, idx % parts, parts);
-    else bps_bits_body<DV>(g, a, s, gb0 + idx / parts, idx % parts, parts);
+    if (checks) bps_checks_body<DC>(g, a, s, bps_grp(s, gc0 + idx / parts), idx % parts, parts);
+    else bps_bits_body<DV>(g, a, s, bps_grp(s, gb0 + idx / parts), idx % parts, parts);
 }
 
 // one wave per group: the iteration is over
 __global__ __launch_bounds__(64) void bps_ctl_advance(BpsState s, uint32_t g0)
 {
-    const size_t grp = g0 + blockIdx.x;
+    const size_t grp = bps_grp(s, g0 + blockIdx.x);
     const uint32_t lane = threadIdx.x;
     const uint64_t act = s.act[grp];
     if ((act >> lane) & 1ull) s.iter[grp * 64 + lane] += 1;
@@ -1576,15 +1593,11 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
     return hipGetLastError();
 }
 
-size_t bp_stream_state_bytes(uint32_t groups) { return (size_t)groups * (5 * 8 + 64 * (4 + 8 + 4)) + 64; }
+size_t bp_stream_state_bytes(uint32_t groups) { return (size_t)groups * (5 * 8 + 64 * (4 + 8 + 4) + 4) + 64; }
 
 // Runs the streamed BP to completion on `st`.  `state` = bp_stream_state_bytes(groups) bytes of device memory.
-hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
-                         uint64_t *rounds_out)
+BpsState bp_stream_state_at(void *state, uint32_t groups)
 {
-    if (!a.n_shots || !groups) return hipSuccess;
-    hipError_t e = hipMemsetAsync(state, 0, bp_stream_state_bytes(groups), st);
-    if (e != hipSuccess) return e;
     BpsState s;
     char *p = (char *)state;
     s.alive = (unsigned long long *)p; p += 64;
@@ -1594,7 +1607,19 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     s.mism = (uint64_t *)p; p += (size_t)groups * 8;
     s.myi = (uint64_t *)p; p += (size_t)groups * 64 * 8;
     s.iter = (uint32_t *)p; p += (size_t)groups * 64 * 4;
-    s.flags = (uint32_t *)p;
+    s.flags = (uint32_t *)p; p += (size_t)groups * 64 * 4;
+    s.gmap_store = (uint32_t *)p;
+    s.gmap = nullptr;
+    return s;
+}
+
+hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
+                         uint64_t *rounds_out, bool resume)
+{
+    if (!a.n_shots || !groups) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (!resume && (e = hipMemsetAsync(state, 0, bp_stream_state_bytes(groups), st)) != hipSuccess) return e;
+    BpsState s = bp_stream_state_at(state, groups);
     // parts: enough blocks to fill the chip a few times over, no more than the work items of the smallest phase
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1605,25 +1630,33 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     // two sets of groups half an iteration apart (see bps_iterate); a single group runs alone
     // Measured at C5: no gain from the skew (a check-update wave keeps its SIMD only 22 % busy, so the check update
     // needs all four wave slots of a SIMD to itself); one set by default, LDPC_HIP_BP_STREAM_SKEW=1 for experiments
-    const bool skew = std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
-    const uint32_t set0[2] = {0, skew ? (groups + 1) / 2 : groups}, setn[2] = {skew ? (groups + 1) / 2 : groups, skew ? groups / 2 : 0};
+    const bool skew = !resume && std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
+    uint32_t set0[2] = {0, skew ? (groups + 1) / 2 : groups}, setn[2] = {skew ? (groups + 1) / 2 : groups, skew ? groups / 2 : 0};
     unsigned long long alive[2] = {0, 0};
     bool wants_checks[2] = {true, true};
+    bool tail = false;   // resume mode after the first round: nothing can be refilled, short control
     // stop test, harvest, refill, set-up, stop test and harvest of the new shots (a zero syndrome stops at once)
     auto control = [&](int t) -> hipError_t {
         const dim3 grid(setn[t] * parts), ctl(setn[t]);
         const uint32_t g0 = set0[t];
-        hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 0);
-        hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 0);
-        hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 0, (unsigned long long *)nullptr);
-        hipLaunchKernelGGL(bps_ctl_refill, ctl, one, 0, st, a, s, g0);
-        hipLaunchKernelGGL(bps_setup_words, grid, blk, 0, st, g, a, s, parts, g0);
-        hipLaunchKernelGGL(bps_setup_synd, grid, blk, 0, st, g, a, s, parts, g0);
-        hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 1);
-        hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 1);
-        hipError_t err = hipMemsetAsync(s.alive + t, 0, 8, st);
-        if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 1, s.alive + t);
+        hipError_t err;
+        if (tail) {
+            hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 0);
+            hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 0);
+            if ((err = hipMemsetAsync(s.alive + t, 0, 8, st)) != hipSuccess) return err;
+            hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 0, s.alive + t);
+        } else {
+            hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 0);
+            hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 0);
+            hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 0, (unsigned long long *)nullptr);
+            hipLaunchKernelGGL(bps_ctl_refill, ctl, one, 0, st, a, s, g0);
+            hipLaunchKernelGGL(bps_setup_words, grid, blk, 0, st, g, a, s, parts, g0);
+            hipLaunchKernelGGL(bps_setup_synd, grid, blk, 0, st, g, a, s, parts, g0);
+            hipLaunchKernelGGL(bps_stop, grid, blk, 0, st, g, a, s, parts, g0, 1);
+            hipLaunchKernelGGL(bps_harvest_words, grid, blk, 0, st, g, a, s, parts, g0, 1);
+            if ((err = hipMemsetAsync(s.alive + t, 0, 8, st)) != hipSuccess) return err;
+            hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 1, s.alive + t);
+        }
         if ((err = hipMemcpyAsync(&alive[t], s.alive + t, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
         return hipStreamSynchronize(st);
     };
@@ -1637,6 +1670,22 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     };
     for (int t = 0; t < 2; t++)
         if (setn[t] && (e = control(t)) != hipSuccess) return e;
+    if (resume && alive[0]) {
+        // tail of the persistent kernel: few groups still hold shots.  List them once (the list only shrinks:
+        // groups that finish later return at once), give each many more parts, and drop refill / set-up from
+        // the round
+        std::vector<uint64_t> act(groups);
+        if ((e = hipMemcpy(act.data(), s.act, (size_t)groups * 8, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        std::vector<uint32_t> list;
+        for (uint32_t i = 0; i < groups; i++)
+            if (act[i]) list.push_back(i);
+        if ((e = hipMemcpy(s.gmap_store, list.data(), list.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        s.gmap = s.gmap_store;
+        setn[0] = (uint32_t)list.size();
+        parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / setn[0]);
+        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+        tail = true;
+    }
     const uint64_t max_rounds = 2 * (((a.n_shots + 64ull * groups - 1) / (64ull * groups) + 1) * ((uint64_t)a.max_iter + 2) + 2);
     uint64_t rounds = 0;
     if (alive[0] && alive[1]) {   // skew the sets: set 0 starts half an iteration early

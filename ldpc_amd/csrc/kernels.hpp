@@ -39,6 +39,17 @@ struct FlipArgs {
     GapTable gap;
 };
 
+// slot state of the streamed BP form (bp_stream_run), device memory: per group u64 masks over its 64 slots,
+// per slot the shot index, iteration count and residual flag
+struct BpsState {
+    unsigned long long *alive;          // [2] per group set: active slots after the round's harvest (host loop condition)
+    uint64_t *act, *fresh, *take, *mism; // [groups]
+    uint64_t *myi;                      // [groups][64]
+    uint32_t *iter, *flags;             // [groups][64]
+    const uint32_t *gmap;               // when set: kernels work on the groups gmap[0..) instead of 0.. (tail)
+    uint32_t *gmap_store;               // [groups] room for that list
+};
+
 struct BpArgs {
     int source;
     int test;
@@ -46,6 +57,12 @@ struct BpArgs {
     uint32_t max_iter;
     uint32_t fail_bit;          // OR-ed into failed_out on failure
     uint32_t profile;           // diagnostics (LDPC_HIP_BP_PROFILE): block 0 prints its cycles per phase
+    // Tail hand-off of the persistent kernel: once the shot queue is drained, a group whose active slots have all
+    // run handoff_iter iterations or more stores its slot state in `handoff` and exits; bp_stream_run(resume)
+    // finishes those shots with the whole chip.  handoff_iter = 0xFFFFFFFF: never.
+    uint32_t handoff_iter;
+    unsigned long long *handoff_flag;   // set to 1 by a group that hands off
+    BpsState handoff;
     double prior;               // ln((1-p)/p), belief_propagation.rs:38
     uint64_t seed, first_shot, n_shots;
     unsigned long long *queue;  // device counter, zero at launch: shots handed out so far
@@ -67,15 +84,6 @@ struct BpArgs {
     uint64_t *ssl;              // [groups][m]      syndromes, bit-sliced over slots
     uint64_t *esl;              // [groups][n]      error words of the slots being refilled, bit-sliced (set-up scratch)
     GapTable gap;
-};
-
-// slot state of the streamed BP form (bp_stream_run), device memory: per group u64 masks over its 64 slots,
-// per slot the shot index, iteration count and residual flag
-struct BpsState {
-    unsigned long long *alive;          // [2] per group set: active slots after the round's harvest (host loop condition)
-    uint64_t *act, *fresh, *take, *mism; // [groups]
-    uint64_t *myi;                      // [groups][64]
-    uint32_t *iter, *flags;             // [groups][64]
 };
 
 // 2-hop neighbourhood table of the flip decoder: for every bit b, K slots of
@@ -111,8 +119,11 @@ uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);
 size_t bp_stream_state_bytes(uint32_t groups);
+// state layout of bp_stream_run inside `state` (bp_stream_state_bytes(groups) bytes)
+BpsState bp_stream_state_at(void *state, uint32_t groups);
+// resume: the state already holds slots handed off by bp_kernel (no reset)
 hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
-                         uint64_t *rounds_out);
+                         uint64_t *rounds_out, bool resume = false);
 hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
 
 }  // namespace ldpc

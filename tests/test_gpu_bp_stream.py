@@ -93,3 +93,29 @@ def test_stream_split_invariance_and_empty(monkeypatch):
     assert ((a + b) == total).all()
     assert dec.mc_run(0.05, 7, 0, 0)[CNT_SHOTS] == 0
     assert dec.mc_run(0.05, 7, 0, 1)[CNT_SHOTS] == 1
+
+
+def test_tail_handoff_changes_nothing(monkeypatch):
+    """Persistent kernel with and without the tail hand-off (shots still running 16 iterations after the queue
+    has drained are finished by the streamed kernels): identical outputs, iteration counts and counters, on a
+    point with many non-converging shots."""
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+    p, shots = 0.14, 3000
+    oc = oracle_code(code)
+    words = np.stack([orc.sample_bsc_words(77, i, p, 1200) for i in range(shots)])
+
+    def run():
+        dec = BpDecoder(code, p, 80)
+        do, di = dev_u64(words.shape), dev_u32((shots,))
+        dec.decode_batch(shots, to_dev_u64(words), do, di)
+        flags = dev_u8((shots,))
+        cnt = dec.mc_run(p, 77, 0, shots, flags)
+        return host_u64(do), host_u32(di), cnt, flags.cpu().numpy()
+
+    out = {}
+    for h in ("0", "16", "1"):
+        monkeypatch.setenv("LDPC_HIP_BP_HANDOFF", h)
+        out[h] = run()
+    monkeypatch.delenv("LDPC_HIP_BP_HANDOFF")
+    assert (out["0"][1] == 80).sum() > 10          # the case has stragglers at the cap
+    assert _same(out["0"], out["16"]) and _same(out["0"], out["1"])
