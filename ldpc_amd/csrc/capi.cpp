@@ -411,7 +411,6 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         if (!std::strcmp(e, "stream")) stream = true;
         else if (!std::strcmp(e, "persistent")) stream = false;
     }
-    if (stream && r.test == TEST_LOGICAL) stream = false;   // CSS failure test: persistent kernel only
     if (stream) groups = std::min<uint64_t>(std::min<uint64_t>(by_memory, 4096), std::max<uint64_t>((r.n_shots + 63) / 64, 1));
     if (std::getenv("LDPC_HIP_DEBUG"))
         std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", stream ? "stream" : "persistent", g.E, waves,
@@ -468,7 +467,10 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         // has drained are finished by the streamed form, the whole chip on the few groups that hold them
         uint32_t handoff = 16;
         if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) handoff = (uint32_t)std::strtoul(e, nullptr, 10);   // 0 = off
-        if (handoff == 0 || r.test == TEST_LOGICAL || dec->max_iter <= handoff) handoff = 0xFFFFFFFFu;
+        // (a streamed round costs about 0.15 ms of launches and one host sync: below E = 3000 a lone group's
+        // iteration is cheaper than that and the tail stays in the persistent kernel; measured at C1 and C3)
+        const bool forced = std::getenv("LDPC_HIP_BP_HANDOFF") != nullptr;
+        if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 3000)) handoff = 0xFFFFFFFFu;
         a.handoff_iter = handoff;
         if (handoff != 0xFFFFFFFFu) {
             HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));

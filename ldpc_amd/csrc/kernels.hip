@@ -1295,6 +1295,22 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, 
         } else if (a.corr_out) a.corr_out[myi * Wn + w] = d;
     }
     if (a.test == TEST_RESIDUAL && rany) atomicOr(&s.flags[grp * 64 + lane], 1u);
+    if (a.test == TEST_LOGICAL) {
+        // CSS half (css/mod.rs:225-252): a logical generator that anticommutes with the residual
+        uint32_t lfail = 0;
+        for (uint32_t r = part * BPS_WAVES + wv; r < a.l_rows; r += parts * BPS_WAVES) {
+            uint32_t par = 0;
+            for (uint32_t k = a.l_ptr[r]; k < a.l_ptr[r + 1]; k++) {
+                const uint32_t b = a.l_idx[k];
+                if (done) {
+                    const size_t off = (size_t)(b >> 6) * 64 + lane;
+                    par ^= (uint32_t)((G.ew[off] ^ G.dw[off]) >> (b & 63)) & 1u;
+                }
+            }
+            lfail |= par;
+        }
+        if (lfail) atomicOr(&s.flags[grp * 64 + lane], 2u);
+    }
     if (a.post_out && done)
         for (uint32_t b = part * BPS_WAVES + wv; b < n; b += parts * BPS_WAVES) {      // BpState::decode posterior, :100-106
             double l = a.prior;
@@ -1316,7 +1332,8 @@ __global__ __launch_bounds__(64) void bps_ctl_harvest(BpArgs a, BpsState s, uint
         const uint64_t donemask = bps_done_mask(a, s, grp, lane, conv);
         const bool done = (donemask >> lane) & 1ull;
         const bool det = !conv;
-        const bool fail = a.test == TEST_RESIDUAL && s.flags[grp * 64 + lane] != 0;
+        const uint32_t fl = s.flags[grp * 64 + lane];
+        const bool fail = a.test == TEST_RESIDUAL ? fl != 0 : a.test == TEST_LOGICAL ? det || (fl & 2u) != 0 : false;
         const uint32_t iter = s.iter[grp * 64 + lane];
         if (done) {
             const uint64_t myi = s.myi[grp * 64 + lane];

@@ -119,3 +119,20 @@ def test_tail_handoff_changes_nothing(monkeypatch):
     monkeypatch.delenv("LDPC_HIP_BP_HANDOFF")
     assert (out["0"][1] == 80).sum() > 10          # the case has stragglers at the cap
     assert _same(out["0"], out["16"]) and _same(out["0"], out["1"])
+
+
+def test_css_counters_same_on_every_path(monkeypatch):
+    """CSS Monte-Carlo (X and Z halves, logical failure test): persistent kernel without hand-off, with hand-off,
+    and the streamed form give the same counters."""
+    from ldpc_amd import CssCode, CssDecoder
+    base = LinearCode.random_regular_code(20, 15, 3, 4, seed=1)
+    css = CssCode.hypergraph_product(base, base)
+    res = []
+    for env in ({"LDPC_HIP_BP_HANDOFF": "0"}, {"LDPC_HIP_BP_HANDOFF": "4"}, {"LDPC_HIP_BP_PATH": "stream"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res.append(CssDecoder(css, 0.04, 60).mc_run(0.04, 5, 0, 6000))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert res[0][CNT_SHOTS] == 6000 and res[0][CNT_FAILURES] > 100
+    assert (res[0] == res[1]).all() and (res[0] == res[2]).all()
