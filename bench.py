@@ -33,7 +33,7 @@ CODE_SEED, NOISE_SEED = 1, 2024
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(code, budget_s=15.0):
+def cpu_baseline(code, budget_s=25.0):
     """The oracle's restatement of FlipDecoder::decode as written in the reference
     (flip.rs:21-43: rescan from bit 0 and a full H*e_bit per flip), timed on this
     host on a bounded sample of the same workload."""
