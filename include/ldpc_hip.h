@@ -112,6 +112,17 @@ int ldpc_code_has_codeword(const ldpc_code *code, size_t len, const size_t *posi
 /* batched H*e on device words: d_words [n_shots][ceil(n/64)] -> d_syndromes [n_shots][ceil(m/64)] */
 int ldpc_code_syndrome_batch(const ldpc_code *code, size_t n_shots, const uint64_t *d_words,
                              uint64_t *d_syndromes);
+/* Host algebra of LinearCode (small codes: dense GF(2) elimination on the host, not part of the decoding path).
+ * generator_matrix() (mod.rs:225-227) is a basis of the nullspace of H computed on demand; the reference's
+ * basis comes from the un-vendored sparse-bin-mat crate, so only its row space is comparable.
+ * num_generators (mod.rs:290-292), dimension (mod.rs:308-310), minimal_distance (mod.rs:318-335; *found = 0
+ * when the code has no non-trivial codeword; LDPC_ERR_CAPACITY above 30 generators), has_same_codespace
+ * (mod.rs:272-275). */
+int ldpc_code_num_generators(const ldpc_code *code, size_t *out);
+int ldpc_code_generator_matrix(const ldpc_code *code, size_t *row_ptr, size_t *col_idx, size_t col_idx_capacity);
+int ldpc_code_dimension(const ldpc_code *code, size_t *out);
+int ldpc_code_minimal_distance(const ldpc_code *code, size_t *distance, int *found);
+int ldpc_code_has_same_codespace(const ldpc_code *code, const ldpc_code *other, int *out);
 void ldpc_code_destroy(ldpc_code *code);
 
 /* ---- noise (src/noise) ------------------------------------------------- */
@@ -128,6 +139,10 @@ int ldpc_depolarizing_sample_error_of_length(double probability, size_t len, uin
  * operator (css.rs:92-99). */
 int ldpc_bsc_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot, size_t n_shots,
                           uint64_t *d_words);
+/* ErasureChannel::with_probability(p).sample_error_of_length(len, rng) (noise/erasure.rs:19-43): the
+ * positions of the erased bits / qubits; the same i.i.d. Bernoulli(p) stream as the binary symmetric channel. */
+int ldpc_erasure_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
+                                        size_t *out_positions, size_t *out_n);
 int ldpc_depolarizing_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot,
                                    size_t n_shots, uint64_t *d_x_words, uint64_t *d_z_words);
 
@@ -198,6 +213,12 @@ int ldpc_css_has_logical(const ldpc_css_code *css, size_t len, const size_t *x_p
                          const size_t *z_part, size_t n_z, int *out);       /* css/mod.rs:225-227 */
 int ldpc_css_has_stabilizer(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x,
                             const size_t *z_part, size_t n_z, int *out);    /* css/mod.rs:247-252 */
+/* CssErasureDecoder (decoders/css_erasure.rs:7-65; host rank algebra, small codes): the numbers of bad X and Z
+ * errors supported on the erasure (:20-57) and ErasureDecoder::recovery_probability = 2^-(bad_x + bad_z) (:60-64) */
+int ldpc_css_erasure_num_bad_errors(const ldpc_css_code *css, size_t len, const size_t *erasure, size_t n_erased,
+                                    size_t *bad_x, size_t *bad_z);
+int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, const size_t *erasure,
+                                          size_t n_erased, double *out);
 void ldpc_css_destroy(ldpc_css_code *css);
 
 /* ---- CssDecoder<BpDecoder> (decoders/css.rs, examples/css_decoding.rs) -- */

@@ -83,7 +83,13 @@ def lib():
         "ldpc_code_syndrome_of": (i, [vp, sz, vp, sz, vp, C.POINTER(sz)]),
         "ldpc_code_has_codeword": (i, [vp, sz, vp, sz, C.POINTER(i)]),
         "ldpc_code_syndrome_batch": (i, [vp, sz, vp, vp]),
+        "ldpc_code_num_generators": (i, [vp, C.POINTER(sz)]),
+        "ldpc_code_generator_matrix": (i, [vp, vp, vp, sz]),
+        "ldpc_code_dimension": (i, [vp, C.POINTER(sz)]),
+        "ldpc_code_minimal_distance": (i, [vp, C.POINTER(sz), C.POINTER(i)]),
+        "ldpc_code_has_same_codespace": (i, [vp, vp, C.POINTER(i)]),
         "ldpc_code_destroy": (None, [vp]),
+        "ldpc_erasure_sample_error_of_length": (i, [dbl, sz, u64, u64, vp, C.POINTER(sz)]),
         "ldpc_bsc_sample_error_of_length": (i, [dbl, sz, u64, u64, vp, C.POINTER(sz)]),
         "ldpc_depolarizing_sample_error_of_length": (i, [dbl, sz, u64, u64, vp, vp, C.POINTER(sz)]),
         "ldpc_bsc_sample_batch": (i, [dbl, sz, u64, u64, sz, vp]),
@@ -111,6 +117,8 @@ def lib():
         "ldpc_css_syndrome_of": (i, [vp, sz, vp, sz, vp, sz, vp, C.POINTER(sz), vp, C.POINTER(sz)]),
         "ldpc_css_has_logical": (i, [vp, sz, vp, sz, vp, sz, C.POINTER(i)]),
         "ldpc_css_has_stabilizer": (i, [vp, sz, vp, sz, vp, sz, C.POINTER(i)]),
+        "ldpc_css_erasure_num_bad_errors": (i, [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "ldpc_css_erasure_recovery_probability": (i, [vp, sz, vp, sz, C.POINTER(dbl)]),
         "ldpc_css_destroy": (None, [vp]),
         "ldpc_css_bp_create": (i, [vp, dbl, sz, pp]),
         "ldpc_css_bp_correction_for": (i, [vp, vp, sz, vp, sz, vp, C.POINTER(sz), vp, C.POINTER(sz)]),
@@ -286,6 +294,40 @@ class LinearCode:
         _check(lib().ldpc_code_edges(self._h, bits.ctypes.data_as(C.c_void_p), checks.ctypes.data_as(C.c_void_p)))
         return [(int(b), int(c)) for b, c in zip(bits[:e], checks[:e])]
 
+    # host algebra (small codes) ---------------------------------------------
+    def num_generators(self):
+        """linear_code/mod.rs:290-292"""
+        k = C.c_size_t(0)
+        _check(lib().ldpc_code_num_generators(self._h, C.byref(k)))
+        return k.value
+
+    def dimension(self):
+        """linear_code/mod.rs:308-310"""
+        k = C.c_size_t(0)
+        _check(lib().ldpc_code_dimension(self._h, C.byref(k)))
+        return k.value
+
+    def generator_matrix(self):
+        """Rows of a basis of the codespace (linear_code/mod.rs:225-227); the basis itself is this library's."""
+        k, n = self.num_generators(), self.len()
+        ptr = np.zeros(k + 1, dtype=np.uintp)
+        idx = np.zeros(max(k * n, 1), dtype=np.uintp)
+        _check(lib().ldpc_code_generator_matrix(self._h, ptr.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                                                idx.size))
+        return _rows_from_csr(ptr, idx)
+
+    def minimal_distance(self):
+        """linear_code/mod.rs:318-335: None if the code has no non-trivial codeword."""
+        d, found = C.c_size_t(0), C.c_int(0)
+        _check(lib().ldpc_code_minimal_distance(self._h, C.byref(d), C.byref(found)))
+        return d.value if found.value else None
+
+    def has_same_codespace(self, other):
+        """linear_code/mod.rs:272-275"""
+        r = C.c_int(0)
+        _check(lib().ldpc_code_has_same_codespace(self._h, other._h, C.byref(r)))
+        return bool(r.value)
+
     # hot path ---------------------------------------------------------------
     def syndrome_of(self, positions, length=None):
         length = self.len() if length is None else length
@@ -334,6 +376,27 @@ class BinarySymmetricChannel:
 
     def __str__(self):
         return "BSC(%s)" % self.probability
+
+
+class ErasureChannel:
+    """noise/erasure.rs:13-49; the sample is the list of erased positions."""
+
+    def __init__(self, probability):
+        self.probability = _pval(probability)
+
+    @staticmethod
+    def with_probability(probability):
+        return ErasureChannel(probability)
+
+    def sample_error_of_length(self, length, seed, shot):
+        out = np.zeros(max(length, 1), dtype=np.uintp)
+        k = C.c_size_t(0)
+        _check(lib().ldpc_erasure_sample_error_of_length(self.probability, int(length), int(seed), int(shot),
+                                                         out.ctypes.data_as(C.c_void_p), C.byref(k)))
+        return [int(x) for x in out[: k.value]]
+
+    def __str__(self):
+        return "Erasure(%s)" % self.probability
 
 
 class DepolarizingNoise:
@@ -572,6 +635,32 @@ class CssCode:
     def random_error(self, noise_model, seed, shot):
         """css/mod.rs:357-363"""
         return noise_model.sample_error_of_length(self.len(), seed, shot)
+
+
+class CssErasureDecoder:
+    """decoders/css_erasure.rs:7-65 (host rank algebra; small codes)."""
+
+    def __init__(self, code):
+        self.code = code
+
+    def _bad(self, erasure):
+        pos, ppos = _szarr(erasure)
+        bx, bz = C.c_size_t(0), C.c_size_t(0)
+        _check(lib().ldpc_css_erasure_num_bad_errors(self.code._h, self.code.len(), ppos, pos.size, C.byref(bx),
+                                                     C.byref(bz)))
+        return bx.value, bz.value
+
+    def num_bad_x_errors(self, erasure):
+        return self._bad(erasure)[0]
+
+    def num_bad_z_errors(self, erasure):
+        return self._bad(erasure)[1]
+
+    def recovery_probability(self, erasure):
+        pos, ppos = _szarr(erasure)
+        p = C.c_double(0.0)
+        _check(lib().ldpc_css_erasure_recovery_probability(self.code._h, self.code.len(), ppos, pos.size, C.byref(p)))
+        return p.value
 
 
 class CssDecoder:

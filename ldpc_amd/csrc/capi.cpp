@@ -625,6 +625,50 @@ int ldpc_code_bit_adjacencies(const ldpc_code *code, size_t *row_ptr, size_t *co
     return LDPC_OK;
 }
 
+// ---- host algebra (small codes) ---------------------------------------------
+int ldpc_code_num_generators(const ldpc_code *code, size_t *out)
+{
+    if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    *out = code->host.len() - gf2_rank(code->host.h);   // rows of a nullspace basis
+    return LDPC_OK;
+}
+
+int ldpc_code_generator_matrix(const ldpc_code *code, size_t *row_ptr, size_t *col_idx, size_t col_idx_capacity)
+{
+    if (!code || !row_ptr) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    const SparseBinMat gmat = nullspace(code->host.h);
+    if (gmat.nnz() > col_idx_capacity || (!col_idx && gmat.nnz()))
+        return fail(LDPC_ERR_CAPACITY, "generator matrix has " + std::to_string(gmat.nnz()) + " ones, buffer holds " +
+                                           std::to_string(col_idx_capacity));
+    export_csr(gmat, row_ptr, col_idx);
+    return LDPC_OK;
+}
+
+int ldpc_code_dimension(const ldpc_code *code, size_t *out)
+{
+    // generator_matrix.rank() (mod.rs:308-310); the rows of a nullspace basis are independent
+    return ldpc_code_num_generators(code, out);
+}
+
+int ldpc_code_minimal_distance(const ldpc_code *code, size_t *distance, int *found)
+{
+    if (!code || !distance || !found) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    uint32_t w = 0;
+    if (!minimal_row_span_weight(nullspace(code->host.h), w))
+        return fail(LDPC_ERR_CAPACITY, "minimal_distance enumerates 2^dimension codewords: dimension above 30");
+    *found = w != 0;
+    *distance = w;
+    return LDPC_OK;
+}
+
+int ldpc_code_has_same_codespace(const ldpc_code *code, const ldpc_code *other, int *out)
+{
+    if (!code || !other || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    // mod.rs:272-275: same length and H * G_other^T == 0
+    *out = code->host.len() == other->host.len() && code->host.h.product_is_zero(nullspace(other->host.h));
+    return LDPC_OK;
+}
+
 int ldpc_code_edges(const ldpc_code *code, size_t *bits, size_t *checks)
 {
     if (!code || ((!bits || !checks) && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
@@ -727,6 +771,13 @@ int ldpc_bsc_sample_error_of_length(double probability, size_t len, uint64_t see
     HIP_TRY(hipStreamSynchronize(g_stream));
     unpack(w, len, out_positions, out_n);
     return LDPC_OK;
+}
+
+int ldpc_erasure_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
+                                        size_t *out_positions, size_t *out_n)
+{
+    // noise/erasure.rs:33-42 draws the same n i.i.d. Bernoulli(p) bits as the binary symmetric channel
+    return ldpc_bsc_sample_error_of_length(probability, len, seed, shot, out_positions, out_n);
 }
 
 int ldpc_depolarizing_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
@@ -1075,6 +1126,32 @@ int ldpc_css_has_stabilizer(const ldpc_css_code *css, size_t len, const size_t *
     st = ldpc_code_syndrome_of(&css->m[3], len, x_part, n_x, nullptr, &b);
     if (st) return st;
     *out = logical && a == 0 && b == 0;
+    return LDPC_OK;
+}
+
+int ldpc_css_erasure_num_bad_errors(const ldpc_css_code *css, size_t len, const size_t *erasure, size_t n_erased,
+                                    size_t *bad_x, size_t *bad_z)
+{
+    if (!css || !bad_x || !bad_z || (n_erased && !erasure)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (len != css->m[0].host.len())
+        return fail(LDPC_ERR_LENGTH_MISMATCH, "erasure of length " + std::to_string(len) + " is invalid for code with length " +
+                                                  std::to_string(css->m[0].host.len()));
+    if (!valid_positions(erasure, n_erased, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
+    std::vector<uint32_t> e(erasure, erasure + n_erased);
+    // css_erasure.rs:20-34: X errors are seen by the Z stabilizers and Z logicals, Z errors by the X ones
+    *bad_x = erasure_num_bad_errors(css->m[1].host.h, css->m[3].host.h, e);
+    *bad_z = erasure_num_bad_errors(css->m[0].host.h, css->m[2].host.h, e);
+    return LDPC_OK;
+}
+
+int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, const size_t *erasure, size_t n_erased,
+                                          double *out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    size_t bx = 0, bz = 0;
+    int st = ldpc_css_erasure_num_bad_errors(css, len, erasure, n_erased, &bx, &bz);
+    if (st) return st;
+    *out = std::ldexp(1.0, -(int)(bx + bz));   // css_erasure.rs:60-64
     return LDPC_OK;
 }
 

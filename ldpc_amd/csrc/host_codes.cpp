@@ -189,6 +189,69 @@ SparseBinMat nullspace(const SparseBinMat &a)
     return out;
 }
 
+static uint32_t rank_of(std::vector<std::vector<uint64_t>> &rows, uint32_t ncols)
+{
+    uint32_t rank = 0;
+    for (uint32_t c = 0; c < ncols && rank < rows.size(); c++) {
+        size_t piv = rank;
+        while (piv < rows.size() && !bit(rows[piv], c)) piv++;
+        if (piv == rows.size()) continue;
+        std::swap(rows[rank], rows[piv]);
+        for (size_t i = rank + 1; i < rows.size(); i++)
+            if (bit(rows[i], c)) xor_into(rows[i], rows[rank]);
+        rank++;
+    }
+    return rank;
+}
+
+uint32_t gf2_rank(const SparseBinMat &a)
+{
+    BitRows m(a.ncols);
+    for (uint32_t r = 0; r < a.nrows(); r++) m.push(a, r);
+    return rank_of(m.r, a.ncols);
+}
+
+bool minimal_row_span_weight(const SparseBinMat &generators, uint32_t &out)
+{
+    const uint32_t k = generators.nrows();
+    if (k > 30) return false;
+    BitRows m(generators.ncols);
+    for (uint32_t r = 0; r < k; r++) m.push(generators, r);
+    std::vector<uint64_t> sum(m.words, 0);
+    uint32_t best = 0;
+    // Gray code: consecutive sums differ by one generator; every non-empty subset is visited once
+    for (uint64_t i = 1; i < (1ull << k); i++) {
+        xor_into(sum, m.r[(size_t)__builtin_ctzll(i)]);
+        uint32_t w = 0;
+        for (uint64_t x : sum) w += (uint32_t)__builtin_popcountll(x);
+        if (w > 0 && (best == 0 || w < best)) best = w;
+    }
+    out = best;
+    return true;
+}
+
+uint32_t erasure_num_bad_errors(const SparseBinMat &stabs, const SparseBinMat &logicals, const std::vector<uint32_t> &erasure)
+{
+    // row e of S: the stabilizers that contain erased qubit e (its syndrome); likewise L; T = [S | L]
+    const SparseBinMat st = stabs.transposed(), lt = logicals.transposed();
+    const uint32_t ns = stabs.nrows(), nl = logicals.nrows();
+    std::vector<std::vector<uint64_t>> S, T;
+    for (uint32_t q : erasure) {
+        std::vector<uint64_t> s((ns + 63) / 64, 0), t((ns + nl + 63) / 64, 0);
+        for (uint32_t e = st.ptr[q]; e < st.ptr[q + 1]; e++) {
+            s[st.idx[e] >> 6] |= 1ull << (st.idx[e] & 63);
+            t[st.idx[e] >> 6] |= 1ull << (st.idx[e] & 63);
+        }
+        for (uint32_t e = lt.ptr[q]; e < lt.ptr[q + 1]; e++) {
+            const uint32_t c = ns + lt.idx[e];
+            t[c >> 6] |= 1ull << (c & 63);
+        }
+        S.push_back(std::move(s));
+        T.push_back(std::move(t));
+    }
+    return rank_of(T, ns + nl) - rank_of(S, ns);
+}
+
 // ---------------------------------------------------------------------------
 // LinearCode
 // ---------------------------------------------------------------------------

@@ -38,6 +38,16 @@ struct SparseBinMat {
 // elimination; host algebra for small codes only).
 SparseBinMat nullspace(const SparseBinMat &a);
 
+// Rank over GF(2) (dense bitset elimination; host algebra for small codes only).
+uint32_t gf2_rank(const SparseBinMat &a);
+// Smallest weight of a non-zero sum of rows of `generators` (LinearCode::minimal_distance,
+// linear_code/mod.rs:318-335: every combination of generator rows).  0 = no non-trivial codeword;
+// returns false when the matrix has more than 30 rows (2^rows sums).
+bool minimal_row_span_weight(const SparseBinMat &generators, uint32_t &out);
+// CssErasureDecoder::num_bad_errors (decoders/css_erasure.rs:38-57): rank([S | L]) - rank(S), S / L = the
+// syndromes / logical syndromes of the single-qubit errors on the erased positions
+uint32_t erasure_num_bad_errors(const SparseBinMat &stabs, const SparseBinMat &logicals, const std::vector<uint32_t> &erasure);
+
 // LinearCode (linear_code/mod.rs:52-56) without the eager generator matrix.
 struct LinearCode {
     SparseBinMat h;    // parity_check_matrix

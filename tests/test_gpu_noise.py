@@ -87,3 +87,14 @@ def test_syndrome_linearity_full_size():
     code.syndrome_batch(shots, a ^ b, sab)
     assert bool(((sa ^ sb) == sab).all())
     assert int((sa != 0).sum()) > 0
+
+
+def test_erasure_channel_is_the_bernoulli_stream():
+    """ErasureChannel (noise/erasure.rs:33-42) draws the same n i.i.d. Bernoulli(p) bits as the BSC."""
+    from ldpc_amd import BinarySymmetricChannel, ErasureChannel
+    for p, n in ((0.1, 500), (0.0, 40), (1.0, 70)):
+        for shot in (0, 5):
+            e = ErasureChannel.with_probability(p).sample_error_of_length(n, 9, shot)
+            assert e == BinarySymmetricChannel(p).sample_error_of_length(n, 9, shot)
+            assert e == sorted(set(e)) and all(0 <= x < n for x in e)
+    assert str(ErasureChannel(0.25)) == "Erasure(0.25)"
