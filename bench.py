@@ -134,15 +134,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; LDPC_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(local_dev)
 
     import ldpc_amd
     from ldpc_amd import FlipDecoder, LinearCode
     from ldpc_amd.dist import all_reduce_counters
 
-    ldpc_amd.set_device(local_rank)
+    ldpc_amd.set_device(local_dev)
     code = LinearCode.random_regular_code(N_BITS, N_CHECKS, DV, DC, seed=CODE_SEED)
     dec = FlipDecoder(code)
     B = args.shots_per_step
@@ -173,7 +179,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     counters = all_reduce_counters(counters)
