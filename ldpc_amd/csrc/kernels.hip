@@ -622,20 +622,14 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 
 
-// update_checks for one check of degree DC (belief_propagation.rs:150-166): x = the incoming bit messages in
-// ascending bit order, out = the outgoing check messages, flip = 0x80000000 when the check's syndrome bit is
-// set (the reference multiplies by -1.0, :160-162).  The edges are worked in batches of HB: enough independent
-// chains to keep the pipeline busy next to the other waves of the SIMD, few enough to stay inside 128 registers.
-template <int DC> __device__ inline void bp_check_row(const double (&x)[DC], uint32_t flip, double (&out)[DC])
+// update_checks for one check of degree DC (belief_propagation.rs:150-166): t = tanh(x/2) of the incoming bit
+// messages in ascending bit order (computed by update_bits, which stores bit messages in that form), out = the
+// outgoing check messages, flip = 0x80000000 when the check's syndrome bit is set (the reference multiplies by
+// -1.0, :160-162).  The edges are worked in batches of HB: enough independent chains to keep the pipeline busy
+// next to the other waves of the SIMD, few enough to stay inside 128 registers.
+template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
 {
     constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : 3;
-    double t[DC];
-#pragma unroll
-    for (int h0 = 0; h0 < DC; h0 += HB) {
-#pragma unroll
-        for (int j = h0; j < h0 + HB && j < DC; j++) t[j] = bp_tanh_half(x[j]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
     double prod = 1.0;
 #pragma unroll
     for (int j = 0; j < DC; j++) prod *= t[j];
@@ -688,7 +682,9 @@ template <int DC> __device__ inline void bp_check_row(const double (&x)[DC], uin
 }
 
 // update_bits (belief_propagation.rs:168-180) + hard decision (:100-113) for the 64 bits of one chunk, all 64
-// slots of the group (lane = slot).  DV > 0: every bit has exactly DV checks.
+// slots of the group (lane = slot).  A bit message m = (sum - check msg) + prior is stored as tanh(m/2), the only
+// form update_checks uses it in (:154,158): the f64 work of an iteration is split between the check update
+// (division, atanh) and this HBM-bound phase.  DV > 0: every bit has exactly DV checks.
 template <int DV>
 __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint32_t lane, bool active, uint64_t actmask,
                                      double prior, const double *chkm, double *bitsm, uint64_t *dw, uint64_t *dsl)
@@ -736,10 +732,13 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint3
                         sum += v[i][k];
                         post += v[i][k];
                     }
+                    double tm[DV];
+#pragma unroll
+                    for (int k = 0; k < DV; k++) tm[k] = bp_tanh_half(sum - v[i][k] + prior);
 #pragma unroll
                     for (int k = 0; k < DV; k++)
                         if (active)
-                            bitsm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + i) * 64 + lane] = sum - v[i][k] + prior;
+                            bitsm[(size_t)__builtin_amdgcn_readlane(myed[k], i0 + i) * 64 + lane] = tm[k];
                     const bool dec = post < 0.0;
                     dacc |= (uint64_t)dec << (i0 + i);
                     const uint64_t mask = __ballot(active && dec);
@@ -763,7 +762,10 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint3
                     }
 #pragma unroll
                 for (uint32_t k = 0; k < REG_DEG; k++)
-                    if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = sum - v[k] + prior;
+                    if (k < dv) {
+                        const double tm = bp_tanh_half(sum - v[k] + prior);
+                        if (active) bitsm[(size_t)ed[k] * 64 + lane] = tm;
+                    }
             } else {
                 for (uint32_t k = 0; k < dv; k++) {
                     double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
@@ -772,7 +774,8 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint3
                 }
                 for (uint32_t k = 0; k < dv; k++) {
                     size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
-                    if (active) bitsm[off] = sum - chkm[off] + prior;
+                    const double tm = bp_tanh_half(sum - chkm[off] + prior);
+                    if (active) bitsm[off] = tm;
                 }
             }
             const bool dec = post < 0.0;
@@ -810,6 +813,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
     uint64_t *ssl = a.ssl + grp * (size_t)m;
     uint64_t *esl = a.esl + grp * (size_t)n;
     const double prior = a.prior;
+    const double t_prior = bp_tanh_half(prior);   // the bit messages of a fresh slot are the prior (:62-66)
 
     // replicated per-slot state (identical in all waves of the group)
     bool drained = false, active = false, fresh = false;
@@ -1020,7 +1024,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
             double xn[DC];
             if (wv < m) {
 #pragma unroll
-                for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)wv * DC + j) * 64 + lane];
+                for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : bitsm[((size_t)wv * DC + j) * 64 + lane];
             }
             for (uint32_t c = wv; c < m; c += NW) {
                 const size_t e0 = (size_t)c * DC;
@@ -1030,7 +1034,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
                 for (int j = 0; j < DC; j++) x[j] = xn[j];
                 if (c + NW < m) {
 #pragma unroll
-                    for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
+                    for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
                 }
                 double out[DC];
                 bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
@@ -1048,8 +1052,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 #pragma unroll
                     for (uint32_t j = 0; j < REG_DEG; j++)
                         if (j < dc) {
-                            double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                            t[j] = bp_tanh_half(x);
+                            t[j] = fresh ? t_prior : bitsm[(size_t)(e0 + j) * 64 + lane];
                             prod *= t[j];
                         }
 #pragma unroll
@@ -1061,13 +1064,10 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
                         }
                 } else {
                     double prod = 1.0;
+                    for (uint32_t j = 0; j < dc; j++) prod *= fresh ? t_prior : bitsm[(size_t)(e0 + j) * 64 + lane];
                     for (uint32_t j = 0; j < dc; j++) {
-                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        prod *= bp_tanh_half(x);
-                    }
-                    for (uint32_t j = 0; j < dc; j++) {
-                        double x = fresh ? prior : bitsm[(size_t)(e0 + j) * 64 + lane];
-                        double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, bp_tanh_half(x)));
+                        const double t = fresh ? t_prior : bitsm[(size_t)(e0 + j) * 64 + lane];
+                        double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, t));
                         if (sbit) v *= -1.0;
                         if (active) chkm[(size_t)(e0 + j) * 64 + lane] = v;
                     }
@@ -1367,13 +1367,13 @@ __device__ inline void bps_checks_body(const DeviceGraph &g, const BpArgs &a, co
     if (!actmask) return;
     const BpsGroup G = bps_group(g, a, grp);
     const bool active = (actmask >> lane) & 1ull, fresh = (s.fresh[grp] >> lane) & 1ull;
-    const double prior = a.prior;
+    const double t_prior = bp_tanh_half(a.prior);
     const uint32_t m = g.m, first = part * BPS_WAVES + wv, step = parts * BPS_WAVES;
     if constexpr (DC > 0) {
         double xn[DC];
         if (first < m) {
 #pragma unroll
-            for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : G.bitsm[((size_t)first * DC + j) * 64 + lane];
+            for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : G.bitsm[((size_t)first * DC + j) * 64 + lane];
         }
         for (uint32_t c = first; c < m; c += step) {
             const size_t e0 = (size_t)c * DC;
@@ -1383,7 +1383,7 @@ __device__ inline void bps_checks_body(const DeviceGraph &g, const BpArgs &a, co
             for (int j = 0; j < DC; j++) x[j] = xn[j];
             if (c + step < m) {
 #pragma unroll
-                for (int j = 0; j < DC; j++) xn[j] = fresh ? prior : G.bitsm[((size_t)(c + step) * DC + j) * 64 + lane];
+                for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : G.bitsm[((size_t)(c + step) * DC + j) * 64 + lane];
             }
             double out[DC];
             bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
@@ -1396,13 +1396,10 @@ __device__ inline void bps_checks_body(const DeviceGraph &g, const BpArgs &a, co
             const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
             const bool sbit = (G.ssl[c] >> lane) & 1ull;
             double prod = 1.0;
+            for (uint32_t j = 0; j < dc; j++) prod *= fresh ? t_prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
             for (uint32_t j = 0; j < dc; j++) {
-                const double x = fresh ? prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
-                prod *= bp_tanh_half(x);
-            }
-            for (uint32_t j = 0; j < dc; j++) {
-                const double x = fresh ? prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
-                double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, bp_tanh_half(x)));
+                const double t = fresh ? t_prior : G.bitsm[(size_t)(e0 + j) * 64 + lane];
+                double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, t));
                 if (sbit) v *= -1.0;
                 if (active) G.chkm[(size_t)(e0 + j) * 64 + lane] = v;
             }
