@@ -309,7 +309,7 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         uint32_t kshift = 0, dvp = 0;
         const char *force = std::getenv("LDPC_HIP_FLIP_KERNEL");   // "csr" forces the generic kernel (tests)
         const bool allow_fast = !(force && std::strcmp(force, "csr") == 0);
-        if (allow_fast && flip2_lds_bytes(g, 16) <= 64 * 1024 && g.n < (1u << 26) &&
+        if (allow_fast && flip2_lds_bytes(g, 16, 1024) <= 64 * 1024 && g.n < (1u << 26) &&
             build_nb_table(dec->code.host, tab, kshift, dvp)) {
             HIP_TRY(dec->nb.reserve(std::max<size_t>(tab.size(), 1) * 4));
             if (!tab.empty()) HIP_TRY(hipMemcpy(dec->nb.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
@@ -331,6 +331,7 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
             a.o_scratch = dec->o_scratch.as<uint64_t>();
         }
         a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
+        if (!a.list_cap) a.list_cap = 512;   // given words: weight unknown
         HIP_TRY(dec->flip_log.reserve((size_t)flip2_max_blocks(g) * 8 * a.flip_log_cap * 4));
         a.flip_log = dec->flip_log.as<uint32_t>();
         KernelTimer timer;
@@ -872,6 +873,7 @@ int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, 
     a.synd_out = d_syndromes_out;
     a.words_out = d_words_out;
     a.gap = make_gap_table(probability);
+    a.list_cap = flip2_list_cap((double)dec->code.host.len() * probability);   // error list sized for the channel
     return run_flip(dec, a, counters);
 }
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -293,8 +294,10 @@ __global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
 // check and cannot be flippable).
 // ---------------------------------------------------------------------------
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr uint32_t LIST_CAP = 512;           // u32 error positions of one shot (8 words never exceed it)
-constexpr uint32_t FLIP2_HDR = 33 + LIST_CAP / 2 + 1;   // u64 words: gap table, list, list counter
+// LDS header of a flip2 block in u64 words: gap table (33), the error-position list of the shot being set up
+// (list_cap u32 entries; a power of two, 64..1024, chosen by the launcher from the expected error weight: LDS
+// bounds the blocks per CU, and a shot with more errors than the list holds takes the piecewise path), counter
+__host__ __device__ constexpr uint32_t flip2_hdr_words(uint32_t list_cap) { return 33 + list_cap / 2 + 1; }
 
 __device__ inline uint32_t row_min_u32(uint32_t v);
 __device__ inline uint32_t half_row_min_u32(uint32_t v);
@@ -381,8 +384,9 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
     const uint32_t per_shot = Wm + Wn + WS;          // LDS words per shot: S, F, FS (O lives in HBM)
     uint32_t *q = (uint32_t *)lds;
     uint32_t *list = (uint32_t *)(lds + 33);         // error positions of the shot being set up
+    const uint32_t LIST_CAP = a.list_cap;
     uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 2);
-    uint64_t *state = lds + FLIP2_HDR;
+    uint64_t *state = lds + flip2_hdr_words(LIST_CAP);
     const NbRec<DVP> *nb = (const NbRec<DVP> *)nbt.rec;
     const uint32_t kshift = ONE ? (G == 16 ? 4u : 3u) : nbt.kshift, K = 1u << kshift;
 
@@ -447,15 +451,16 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
                                 }
                 }
             } else {
-                // more errors than the list holds (large p): same two passes over 16-word pieces of the
-                // word, each piece (<= 1024 positions) listed in turn
+                // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words,
+                // each piece (<= LIST_CAP positions) listed in turn
+                const uint32_t pw = LIST_CAP / 64;
                 for (int pass = 0; pass < 2; pass++) {
-                    for (uint32_t wb = 0; wb < Wn; wb += 8) {
+                    for (uint32_t wb = 0; wb < Wn; wb += pw) {
                         wave_order();
                         if (lane == 0) *cnt_lds = 0;
                         wave_order();
                         const uint32_t w = wb + lane;
-                        uint64_t x = (lane < 8 && w < Wn) ? O[w] : 0;
+                        uint64_t x = (lane < pw && w < Wn) ? O[w] : 0;
                         const uint32_t cc = (uint32_t)__builtin_popcountll(x);
                         if (cc) {
                             uint32_t off = atomicAdd(cnt_lds, cc);
@@ -1518,10 +1523,10 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot)
+size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot, uint32_t list_cap)
 {
     size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    return (FLIP2_HDR + (64 / lanes_per_shot) * (Wm + Wn + (2 * Wn + 63) / 64)) * 8;
+    return (flip2_hdr_words(list_cap) + (64 / lanes_per_shot) * (Wm + Wn + (2 * Wn + 63) / 64)) * 8;
 }
 
 uint32_t flip2_lanes_per_shot(const DeviceGraph &g)
@@ -1532,12 +1537,24 @@ uint32_t flip2_lanes_per_shot(const DeviceGraph &g)
     return 16u;
 }
 
-uint32_t flip2_max_blocks(const DeviceGraph &g)
+// list capacity for an expected error weight: the next power of two above mean + 4 sigma, within [64, 1024]
+uint32_t flip2_list_cap(double expected_weight)
+{
+    const double want = expected_weight + 4.0 * std::sqrt(expected_weight > 0 ? expected_weight : 0.0);
+    uint32_t cap = 64;
+    while (cap < 1024 && (double)cap < want) cap <<= 1;
+    return cap;
+}
+
+static uint32_t flip2_blocks_for(const DeviceGraph &g, uint32_t list_cap)
 {
     // one wave per block; blocks per CU limited by LDS (160 KiB) and by 8 waves per SIMD
     const uint32_t lanes = flip2_lanes_per_shot(g);
-    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g, lanes));
+    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g, lanes, list_cap));
 }
+
+// upper bound on the blocks of any launch (scratch sizing): the smallest list
+uint32_t flip2_max_blocks(const DeviceGraph &g) { return flip2_blocks_for(g, 64); }
 
 template <int DVP, int G>
 static void launch_flip2_t(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, uint32_t grid, size_t lds, hipStream_t st)
@@ -1565,9 +1582,9 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
 {
     if (!a.n_shots) return hipSuccess;
     const uint32_t lanes = flip2_lanes_per_shot(g);
-    const size_t lds = flip2_lds_bytes(g, lanes);
+    const size_t lds = flip2_lds_bytes(g, lanes, a.list_cap);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_max_blocks(g));
+    const uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_blocks_for(g, a.list_cap));
     if (nb.dvp == 3) {
         if (lanes == 8) launch_flip2_t<3, 8>(g, nb, a, grid, lds, st);
         else launch_flip2_t<3, 16>(g, nb, a, grid, lds, st);

@@ -36,6 +36,7 @@ struct FlipArgs {
     uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][shots per wave][Wn] parked input words when errors_out is null
     uint32_t *flip_log;         // fast kernel: [flip2_max_blocks][shots per wave][flip_log_cap] flipped bits
     uint32_t flip_log_cap;      // >= m rounded up to 16, + 16
+    uint32_t list_cap;          // fast kernel: entries of the LDS error list (flip2_list_cap)
     GapTable gap;
 };
 
@@ -98,7 +99,8 @@ struct NbTable {
 };
 
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
-size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot);
+size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot, uint32_t list_cap);
+uint32_t flip2_list_cap(double expected_weight);
 uint32_t flip2_lanes_per_shot(const DeviceGraph &g);
 uint32_t flip2_max_blocks(const DeviceGraph &g);
 
