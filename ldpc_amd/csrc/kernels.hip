@@ -751,42 +751,95 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint3
                 }
         }
     } else {
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t k0 = g.t_ptr[b], dv = g.t_ptr[b + 1] - k0;
+        // any degrees.  The chunk's edge-list bounds (lane i = bit b0 + i) and, when they fit four registers
+        // (<= 256 edges in the chunk), the edge list itself are fetched once and read back as scalars, so row
+        // addresses are scalar and no row load waits on an index load; the rows of the next bit are in flight
+        // while the current bit is worked.
+        const uint32_t nbits = b1 - b0;
+        const uint32_t myk0 = b0 + lane < b1 ? g.t_ptr[b0 + lane] : 0u, myk1 = b0 + lane < b1 ? g.t_ptr[b0 + lane + 1] : 0u;
+        const uint32_t kstart = __builtin_amdgcn_readlane(myk0, 0), cnt = __builtin_amdgcn_readlane(myk1, nbits - 1) - kstart;
+        const bool listed = cnt <= 256;
+        uint32_t me[4] = {0, 0, 0, 0};
+        if (listed) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (lane + 64 * j < cnt) me[j] = g.t_edge[kstart + lane + 64 * j];
+        }
+        auto edge = [&](uint32_t k) -> uint32_t {   // k wave-uniform
+            if (!listed) return __builtin_amdgcn_readfirstlane(g.t_edge[k]);
+            const uint32_t o = k - kstart, l = o & 63, qd = o >> 6;
+            const uint32_t a0 = __builtin_amdgcn_readlane(me[0], l), a1 = __builtin_amdgcn_readlane(me[1], l),
+                           a2 = __builtin_amdgcn_readlane(me[2], l), a3 = __builtin_amdgcn_readlane(me[3], l);
+            return qd == 0 ? a0 : qd == 1 ? a1 : qd == 2 ? a2 : a3;
+        };
+        double vn[REG_DEG];
+        uint32_t edn[REG_DEG];
+#pragma unroll
+        for (uint32_t k = 0; k < REG_DEG; k++) {
+            vn[k] = 0.0;
+            edn[k] = 0;
+        }
+        uint32_t k0n = kstart, dvn = nbits ? __builtin_amdgcn_readlane(myk1, 0) - kstart : 0u;
+        if (dvn <= REG_DEG) {
+#pragma unroll
+            for (uint32_t k = 0; k < REG_DEG; k++)
+                if (k < dvn) {
+                    edn[k] = edge(k0n + k);
+                    vn[k] = chkm[(size_t)edn[k] * 64 + lane];
+                }
+        }
+        for (uint32_t i = 0; i < nbits; i++) {
+            const uint32_t k0 = k0n, dv = dvn;
             double sum = 0.0, post = prior;
+            double v[REG_DEG];
+            uint32_t ed[REG_DEG];
+#pragma unroll
+            for (uint32_t k = 0; k < REG_DEG; k++) {
+                v[k] = vn[k];
+                ed[k] = edn[k];
+            }
+            if (i + 1 < nbits) {
+                k0n = __builtin_amdgcn_readlane(myk0, i + 1);
+                dvn = __builtin_amdgcn_readlane(myk1, i + 1) - k0n;
+                if (dvn <= REG_DEG) {
+#pragma unroll
+                    for (uint32_t k = 0; k < REG_DEG; k++)
+                        if (k < dvn) {
+                            edn[k] = edge(k0n + k);
+                            vn[k] = chkm[(size_t)edn[k] * 64 + lane];
+                        }
+                }
+            }
             if (dv <= REG_DEG) {
-                double v[REG_DEG];
-                uint32_t ed[REG_DEG];
 #pragma unroll
                 for (uint32_t k = 0; k < REG_DEG; k++)
                     if (k < dv) {
-                        ed[k] = g.t_edge[k0 + k];
-                        v[k] = chkm[(size_t)ed[k] * 64 + lane];
                         sum += v[k];
                         post += v[k];
                     }
+                double tm[REG_DEG];
 #pragma unroll
                 for (uint32_t k = 0; k < REG_DEG; k++)
-                    if (k < dv) {
-                        const double tm = bp_tanh_half(sum - v[k] + prior);
-                        if (active) bitsm[(size_t)ed[k] * 64 + lane] = tm;
-                    }
+                    if (k < dv) tm[k] = bp_tanh_half(sum - v[k] + prior);
+#pragma unroll
+                for (uint32_t k = 0; k < REG_DEG; k++)
+                    if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = tm[k];
             } else {
                 for (uint32_t k = 0; k < dv; k++) {
-                    double v = chkm[(size_t)g.t_edge[k0 + k] * 64 + lane];
-                    sum += v;
-                    post += v;
+                    const double vv = chkm[(size_t)edge(k0 + k) * 64 + lane];
+                    sum += vv;
+                    post += vv;
                 }
                 for (uint32_t k = 0; k < dv; k++) {
-                    size_t off = (size_t)g.t_edge[k0 + k] * 64 + lane;
+                    const size_t off = (size_t)edge(k0 + k) * 64 + lane;
                     const double tm = bp_tanh_half(sum - chkm[off] + prior);
                     if (active) bitsm[off] = tm;
                 }
             }
             const bool dec = post < 0.0;
-            dacc |= (uint64_t)dec << (b & 63);
-            uint64_t mask = __ballot(active && dec);
-            if (lane == (b & 63)) slice = mask;
+            dacc |= (uint64_t)dec << i;
+            const uint64_t mask = __ballot(active && dec);
+            if (lane == i) slice = mask;
         }
     }
     if (active) dw[(size_t)chunk * 64 + lane] = dacc;
