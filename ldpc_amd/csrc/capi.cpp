@@ -389,9 +389,9 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t budget = std::min<size_t>((size_t)((double)(free_b + dec->workspace.bytes) * 0.75), (size_t)200 << 30);
-    // measured (scripts/bp_probe.py): C2 (E = 30000) and C1 (E = 3600) run fastest with 8 waves per
-    // group, the 625-qubit HGP code (E = 2100) with 4: shorter iterations, shorter straggler tail
-    const uint32_t waves_default = g.E <= 256 ? 1u : g.E <= 1024 ? 2u : g.E <= 3000 ? 4u : 8u;
+    // measured (scripts/bp_probe.py, scripts/css_one.py): C2 (E = 30000), C1 (E = 3600) and the 625-qubit HGP code
+    // (E = 2100 per half) all run fastest with 8 waves per group: shorter iterations, shorter straggler tail
+    const uint32_t waves_default = g.E <= 256 ? 1u : g.E <= 1024 ? 2u : 8u;
     uint32_t waves = waves_default;
     if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(8, std::atoi(e)));   // A/B aid
     // only as many groups as are resident at once: a queued workgroup would find the shot queue drained
