@@ -443,12 +443,22 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
                 }
                 wave_order();
                 // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
-                for (uint32_t t = lane; t < (total << kshift); t += 64) {
-                    const NbRec<DVP> r = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
-                    if (r.bit != NONE && rec_flippable<DVP, REG>(r, S32)) {
-                                    atomicOr(&F32[r.bit >> 5], 1u << (r.bit & 31));
-                                    atomicOr(&FS32[r.bit >> 10], 1u << ((r.bit >> 5) & 31));
-                                }
+                // (four records per trip: their row loads are in flight together)
+                constexpr uint32_t P2 = 4;
+                for (uint32_t t0 = lane; t0 < (total << kshift); t0 += 64 * P2) {
+                    NbRec<DVP> r[P2];
+#pragma unroll
+                    for (uint32_t u = 0; u < P2; u++) {
+                        const uint32_t t = t0 + 64 * u;
+                        r[u].bit = NONE;
+                        if (t < (total << kshift)) r[u] = nb[((size_t)list[t >> kshift] << kshift) + (t & (K - 1))];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < P2; u++)
+                        if (r[u].bit != NONE && rec_flippable<DVP, REG>(r[u], S32)) {
+                            atomicOr(&F32[r[u].bit >> 5], 1u << (r[u].bit & 31));
+                            atomicOr(&FS32[r[u].bit >> 10], 1u << ((r[u].bit >> 5) & 31));
+                        }
                 }
             } else {
                 // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words,
