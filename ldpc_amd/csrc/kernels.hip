@@ -435,11 +435,19 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
             const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
             if (total <= LIST_CAP) {
                 // pass 1, syndrome: toggle the checks of every error bit (slot 0 of its row)
-                for (uint32_t t = lane; t < total; t += 64) {
-                    const NbRec<DVP> r = nb[(size_t)list[t] << kshift];
+                for (uint32_t t0 = lane; t0 < total; t0 += 64 * 4) {
+                    NbRec<DVP> r[4];
 #pragma unroll
-                    for (int k = 0; k < DVP; k++)
-                        if (r.chk[k] != NONE) atomicXor(chk_word(S32, r.chk[k]), chk_mask(r.chk[k]));
+                    for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int k = 0; k < DVP; k++) r[u].chk[k] = NONE;
+                        if (t0 + 64 * u < total) r[u] = nb[(size_t)list[t0 + 64 * u] << kshift];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+#pragma unroll
+                        for (int k = 0; k < DVP; k++)
+                            if (r[u].chk[k] != NONE) atomicXor(chk_word(S32, r[u].chk[k]), chk_mask(r[u].chk[k]));
                 }
                 wave_order();
                 // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
@@ -594,9 +602,14 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
                 // device-scope loads: both were written by this wave, possibly through another lane
                 for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&Ej[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wave_order();
-                for (uint32_t t = lane; t < nf; t += 64) {
-                    const uint32_t b = __hip_atomic_load(&lj[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicXor(&O32[b >> 5], 1u << (b & 31));                // flip.rs:30
+                for (uint32_t t0 = lane; t0 < nf; t0 += 64 * 4) {
+                    uint32_t bb[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        bb[u] = t0 + 64 * u < nf ? __hip_atomic_load(&lj[t0 + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        if (bb[u] != NONE) atomicXor(&O32[bb[u] >> 5], 1u << (bb[u] & 31));                // flip.rs:30
                 }
                 wave_order();
                 uint64_t anyo = 0, anys = 0;
