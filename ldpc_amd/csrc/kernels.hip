@@ -102,7 +102,40 @@ __global__ __launch_bounds__(256) void sample_depol_kernel(GapTable gap, uint32_
     }
 }
 
-// one wave per shot, one lane per check row, 64 parities -> one ballot word
+// H*e, sparse form: one wave per shot, the syndrome accumulates in the wave's LDS slice; the lanes walk the set
+// bits of their words and toggle the checks of each (bit_adjacencies row) with LDS atomics.  Work follows the
+// weight of e (C2 at p = 0.02: 200 bits x 3 checks) instead of the m x dc gathers of the row-wise form below.
+__global__ __launch_bounds__(256) void syndrome_sparse_kernel(DeviceGraph g, uint64_t n_shots, const uint64_t *words,
+                                                              uint64_t *synd)
+{
+    extern __shared__ uint64_t lds[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    uint64_t *S = lds + (size_t)wv * Wm;
+    uint32_t *S32 = (uint32_t *)S;
+    for (uint64_t i = (uint64_t)blockIdx.x * nw + wv; i < n_shots; i += (uint64_t)gridDim.x * nw) {
+        for (uint32_t w = lane; w < Wm; w += 64) S[w] = 0;
+        wave_sync();
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            uint64_t x = words[i * Wn + w];
+            const uint32_t nb = bits_in_word(g.n, w);
+            if (nb < 64) x &= (1ull << nb) - 1;
+            while (x) {
+                const uint32_t b = (w << 6) + (uint32_t)__builtin_ctzll(x);
+                x &= x - 1;
+                for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) {
+                    const uint32_t c = g.t_idx[k];
+                    atomicXor(&S32[c >> 5], 1u << (c & 31));
+                }
+            }
+        }
+        wave_sync();
+        for (uint32_t w = lane; w < Wm; w += 64) synd[i * Wm + w] = S[w];
+        wave_sync();
+    }
+}
+
+// row-wise form (syndromes larger than LDS): one wave per shot, one lane per check row, 64 parities -> one ballot word
 __global__ __launch_bounds__(256) void syndrome_kernel(DeviceGraph g, uint64_t n_shots, const uint64_t *words,
                                                        uint64_t *synd)
 {
@@ -1578,7 +1611,14 @@ hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_
                            hipStream_t st)
 {
     if (!n_shots || !g.m) return hipSuccess;
-    hipLaunchKernelGGL(syndrome_kernel, dim3(grid_for(n_shots, 4, 8192)), dim3(256), 0, st, g, n_shots, d_words, d_synd);
+    const size_t per_wave = (size_t)((g.m + 63) / 64) * 8;
+    uint32_t nw = 4;
+    while (nw > 1 && nw * per_wave > 48 * 1024) nw >>= 1;
+    if (nw * per_wave <= 64 * 1024)
+        hipLaunchKernelGGL(syndrome_sparse_kernel, dim3(grid_for(n_shots, nw, 16384)), dim3(64 * nw), nw * per_wave, st, g,
+                           n_shots, d_words, d_synd);
+    else
+        hipLaunchKernelGGL(syndrome_kernel, dim3(grid_for(n_shots, 4, 8192)), dim3(256), 0, st, g, n_shots, d_words, d_synd);
     return hipGetLastError();
 }
 
