@@ -40,7 +40,13 @@ def test_flip_mc_counters_c1_full():
 
 
 @pytest.mark.parametrize("n,m,dv,dc,p,shots", [(1200, 900, 3, 4, 0.02, 512), (10000, 5000, 3, 6, 0.02, 256),
-                                               (10000, 5000, 3, 6, 0.05, 64), (4, 3, 3, 4, 0.2, 64)])
+                                               (10000, 5000, 3, 6, 0.05, 64), (4, 3, 3, 4, 0.2, 64),
+                                               # more summary words than lanes per shot: the scan-cursor path
+                                               (40000, 20000, 3, 6, 0.012, 24), (20000, 15000, 3, 4, 0.03, 24),
+                                               # 21 and 13 neighbours: two rounds per flip / 7-check records
+                                               (3000, 2000, 4, 6, 0.03, 96), (3000, 1500, 2, 4, 0.04, 96),
+                                               # weight far above the error list: piecewise set-up
+                                               (10000, 5000, 3, 6, 0.2, 24)])
 def test_flip_matches_oracle(n, m, dv, dc, p, shots):
     code = LinearCode.random_regular_code(n, m, dv, dc, seed=1)
     oc = oracle_code(code)
