@@ -413,6 +413,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         else if (!std::strcmp(e, "persistent")) stream = false;
     }
     if (stream) groups = std::min<uint64_t>(std::min<uint64_t>(by_memory, 4096), std::max<uint64_t>((r.n_shots + 63) / 64, 1));
+    if (const char *e = std::getenv("LDPC_HIP_BP_GROUPS"))   // A/B aid (streamed form only: the persistent grid must stay resident)
+        if (stream) groups = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)std::atoll(e)));
     if (std::getenv("LDPC_HIP_DEBUG"))
         std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);

@@ -136,3 +136,26 @@ def test_css_counters_same_on_every_path(monkeypatch):
             monkeypatch.delenv(k)
     assert res[0][CNT_SHOTS] == 6000 and res[0][CNT_FAILURES] > 100
     assert (res[0] == res[1]).all() and (res[0] == res[2]).all()
+
+
+def test_c5_full_size_properties():
+    """BASELINE.json configs[4]: (3,6)-regular n = 10^6 (3 GB of messages per 64-shot group: the streamed form is the
+    default there).  No oracle at this size in test time; size-independent properties instead: BP stops before the
+    cap on every shot at p = 0.02, the correction reproduces the syndrome (H c = s), and since the code corrects
+    this weight the correction IS the error (zero residual, no failures counted)."""
+    from ldpc_amd import BinarySymmetricChannel
+    n, m, shots, p = 1000000, 500000, 192, 0.02
+    code = LinearCode.random_regular_code(n, m, 3, 6, seed=1)
+    dec = BpDecoder(code, p, 100)
+    de, ds = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m)))
+    BinarySymmetricChannel(p).sample_batch(n, 31, 0, shots, de)
+    code.syndrome_batch(shots, de, ds)
+    dc, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+    dec.correction_for_batch(shots, ds, dc, di)
+    assert int(di.max()) < 100 and int(di.min()) >= 1
+    chk = dev_u64((shots, nwords(m)))
+    code.syndrome_batch(shots, dc, chk)
+    assert bool((chk == ds).all())
+    assert bool((dc == de).all())
+    cnt = dec.mc_run(p, 31, 0, shots)
+    assert cnt[CNT_SHOTS] == shots and cnt[CNT_FAILURES] == 0 and cnt[CNT_WORK] == int(di.sum())
