@@ -100,6 +100,7 @@ GapTable make_gap_table(double p)
         t.q[j] = f >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)f;
     }
     t.p_is_zero = p == 0.0;
+    t.inv_log2q = (p > 0.0 && p < 1.0) ? (float)(1.0 / std::log2(1.0 - p)) : 0.0f;
     return t;
 }
 

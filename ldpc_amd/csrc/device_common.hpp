@@ -26,6 +26,7 @@ struct DeviceGraph {
 struct GapTable {
     uint32_t q[65];
     uint32_t p_is_zero;
+    float inv_log2q;   // 1 / log2(1 - p) (0 when p == 1): starting point of gap_of's table search
 };
 
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -72,20 +73,27 @@ struct DrawStream {
     }
 };
 
-// gap(u) = #{ j in 1..64 : u < q[j] }, q non-increasing.  `q` may live in LDS or
-// global memory.
-__device__ inline uint32_t gap_of(const uint32_t *q, uint32_t u)
+// gap(u) = #{ j in 1..64 : u < q[j] }, q non-increasing.  `q` may live in LDS or global memory.
+// The count is the largest j with u < q[j]; q[j] ~ (1-p)^j 2^32, so j ~ (log2(u) - 32) / log2(1-p): a float
+// estimate picks the starting index and the table decides (the result is exact whatever the estimate; a good
+// one costs one round trip to the table instead of the six of a binary search).
+__device__ inline uint32_t gap_of(const uint32_t *q, float inv_log2q, uint32_t u)
 {
-    uint32_t g = 0;
-#pragma unroll
-    for (uint32_t step = 32; step >= 1; step >>= 1)
-        if (u < q[g + step]) g += step;
-    if (g == 63 && u < q[64]) g = 64;
-    return g;
+    const float est = (__log2f((float)u) - 32.0f) * inv_log2q;       // u = 0: +inf; p = 1: NaN -> 0 below
+    uint32_t j = (uint32_t)fminf(fmaxf(est, 0.0f), 64.0f);
+    const uint32_t a = q[j], b = q[j < 64 ? j + 1 : 64];
+    if (j < 64 && u < b) {
+        do j++;
+        while (j < 64 && u < q[j + 1]);
+    } else if (j > 0 && !(u < a)) {
+        do j--;
+        while (j > 0 && !(u < q[j]));
+    }
+    return j;
 }
 
 // One 64-bit word of a BSC sample (binary_symmetric_channel.rs:35-43 distribution).
-__device__ inline uint64_t bsc_word(const uint32_t *q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
+__device__ inline uint64_t bsc_word(const uint32_t *q, float inv_log2q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
                                     uint32_t nbits)
 {
     if (p_is_zero) return 0;
@@ -94,7 +102,7 @@ __device__ inline uint64_t bsc_word(const uint32_t *q, bool p_is_zero, uint64_t 
     uint64_t word = 0;
     uint32_t pos = 0;
     for (;;) {
-        pos += gap_of(q, s.draw());
+        pos += gap_of(q, inv_log2q, s.draw());
         if (pos >= nbits) break;
         word |= 1ull << pos;
         pos++;
@@ -105,7 +113,7 @@ __device__ inline uint64_t bsc_word(const uint32_t *q, bool p_is_zero, uint64_t 
 
 // One word of a depolarizing sample (depolarizing.rs:34-48): x part = X or Y,
 // z part = Z or Y (css.rs:92-99).
-__device__ inline void depol_word(const uint32_t *q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
+__device__ inline void depol_word(const uint32_t *q, float inv_log2q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
                                   uint32_t nbits, uint64_t &xw, uint64_t &zw)
 {
     xw = 0; zw = 0;
@@ -114,7 +122,7 @@ __device__ inline void depol_word(const uint32_t *q, bool p_is_zero, uint64_t se
     s.init(seed, shot, w);
     uint32_t pos = 0;
     for (;;) {
-        pos += gap_of(q, s.draw());
+        pos += gap_of(q, inv_log2q, s.draw());
         if (pos >= nbits) break;
         uint32_t pauli = (uint32_t)(((uint64_t)s.draw() * 3u) >> 32);   // 0 = X, 1 = Y, 2 = Z
         if (pauli <= 1) xw |= 1ull << pos;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void sample_bsc_kernel(GapTable gap, uint32_t 
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t i = t / Wn;
         uint32_t w = (uint32_t)(t - i * Wn);
-        words[t] = bsc_word(q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w));
+        words[t] = bsc_word(q, gap.inv_log2q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w));
     }
 }
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sample_depol_kernel(GapTable gap, uint32_
         uint64_t i = t / Wn;
         uint32_t w = (uint32_t)(t - i * Wn);
         uint64_t x, z;
-        depol_word(q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w), x, z);
+        depol_word(q, gap.inv_log2q, gap.p_is_zero, seed, first + i, w, bits_in_word(n, w), x, z);
         xw[t] = x;
         zw[t] = z;
     }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
         for (uint32_t w = lane; w < Wn; w += 64) {
             uint32_t nb = bits_in_word(g.n, w);
             uint64_t x;
-            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
             else {
                 x = a.words_in[i * Wn + w];
                 if (nb < 64) x &= (1ull << nb) - 1;
@@ -448,7 +448,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
             for (uint32_t w = lane; w < Wn; w += 64) {
                 const uint32_t nb_bits = bits_in_word(g.n, w);
                 uint64_t x;
-                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
+                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
                 else {
                     x = a.words_in[i * Wn + w];
                     if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
@@ -967,13 +967,13 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
                         uint64_t x = 0;
                         if (take) {
                             uint32_t nb = bits_in_word(n, w);
-                            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+                            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
                             else if (a.source == SRC_WORDS) {
                                 x = a.words_in[myi * Wn + w];
                                 if (nb < 64) x &= (1ull << nb) - 1;
                             } else {
                                 uint64_t xx, zz;
-                                depol_word(q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
+                                depol_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
                                 x = a.source == SRC_DEPOL_X ? xx : zz;
                             }
                             ew[(size_t)w * 64 + lane] = x;
@@ -1305,13 +1305,13 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_words(DeviceGraph g, Bp
         if (a.source != SRC_SYNDROMES) {
             uint64_t x = 0;
             if (take) {
-                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.p_is_zero, a.seed, shot, w, nb);
+                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
                 else if (a.source == SRC_WORDS) {
                     x = a.words_in[myi * Wn + w];
                     if (nb < 64) x &= (1ull << nb) - 1;
                 } else {
                     uint64_t xx, zz;
-                    depol_word(q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
+                    depol_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
                     x = a.source == SRC_DEPOL_X ? xx : zz;
                 }
                 G.ew[(size_t)w * 64 + lane] = x;
