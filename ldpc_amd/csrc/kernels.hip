@@ -747,12 +747,18 @@ template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uin
 // form update_checks uses it in (:154,158): the f64 work of an iteration is split between the check update
 // (division, atanh) and this HBM-bound phase.  DV > 0: every bit has exactly DV checks.
 template <int DV>
-__device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint32_t lane, bool active, uint64_t actmask,
-                                     double prior, const double *chkm, double *bitsm, uint64_t *dw, uint64_t *dsl)
+__device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32_t split, uint32_t lane, bool active,
+                                     uint64_t actmask, double prior, const double *chkm, double *bitsm, uint64_t *dw,
+                                     uint64_t *dsl)
 {
+    // item = chunk * split + piece: a 64-bit chunk is worked in `split` (1, 2 or 4) pieces, so that codes with
+    // few chunks still spread evenly over the waves of a group
     const uint32_t n = g.n;
     uint64_t dacc = 0, slice = 0;
-    const uint32_t b0 = chunk * 64, b1 = b0 + 64 < n ? b0 + 64 : n;
+    const uint32_t chunk = item / split, piece = item % split, width = 64 / split;
+    const uint32_t b0 = chunk * 64 + piece * width;
+    if (b0 >= n) return;
+    const uint32_t b1 = b0 + width < n ? b0 + width : n;
     if constexpr (DV > 0) {
         // the chunk's edge lists are fetched once, lane i holding those of bit b0 + i; the loop below
         // reads them back as scalars (readlane), so every row address is scalar base + lane offset and
@@ -898,7 +904,11 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t chunk, uint3
             if (lane == i) slice = mask;
         }
     }
-    if (active) dw[(size_t)chunk * 64 + lane] = dacc;
+    if (active) {
+        if (split == 1) dw[(size_t)chunk * 64 + lane] = dacc;
+        else if (split == 2) ((uint32_t *)dw)[((size_t)chunk * 64 + lane) * 2 + piece] = (uint32_t)dacc;
+        else ((uint16_t *)dw)[((size_t)chunk * 64 + lane) * 4 + piece] = (uint16_t)dacc;
+    }
     const uint32_t bb = b0 + lane;
     if (bb < b1) dsl[bb] = (dsl[bb] & ~actmask) | slice;
 }
@@ -1191,8 +1201,11 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
         __syncthreads();
         lap(3);
         // update_bits (:168-180) + hard decision (:100-113): the waves take 64-bit chunks round-robin
-        for (uint32_t chunk = wv; chunk < Wn; chunk += NW)
-            bp_bits_chunk<DV>(g, chunk, lane, active, actmask, prior, chkm, bitsm, dw, dsl);
+        {
+            const uint32_t split = Wn >= 4 * NW ? 1u : Wn >= 2 * NW ? 2u : 4u;
+            for (uint32_t item = wv; item < Wn * split; item += NW)
+                bp_bits_chunk<DV>(g, item, split, lane, active, actmask, prior, chkm, bitsm, dw, dsl);
+        }
         if (active) { iter++; fresh = false; }
         __syncthreads();
         lap(4);
@@ -1532,7 +1545,7 @@ __device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, cons
     const bool active = (actmask >> lane) & 1ull;
     const uint32_t Wn = (g.n + 63) / 64;
     for (uint32_t chunk = part * BPS_WAVES + wv; chunk < Wn; chunk += parts * BPS_WAVES)
-        bp_bits_chunk<DV>(g, chunk, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
+        bp_bits_chunk<DV>(g, chunk, 1, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
 }
 
 // One half-step of the streamed form: update_checks on the groups [gc0, gc0 + gcn) and update_bits on the
