@@ -24,6 +24,14 @@ pub struct ldpc_flip_decoder {
 pub struct ldpc_bp_decoder {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct ldpc_css_code {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct ldpc_css_bp_decoder {
+    _private: [u8; 0],
+}
 
 pub const LDPC_COUNTERS: usize = 8;
 
@@ -90,6 +98,29 @@ extern "C" {
         d_failed_out: *mut u8,
     ) -> c_int;
     fn ldpc_bp_destroy(dec: *mut ldpc_bp_decoder);
+    fn ldpc_css_create_with_logicals(
+        x_stabs: *const ldpc_code,
+        z_stabs: *const ldpc_code,
+        x_logicals: *const ldpc_code,
+        z_logicals: *const ldpc_code,
+        out: *mut *mut ldpc_css_code,
+    ) -> c_int;
+    fn ldpc_css_destroy(css: *mut ldpc_css_code);
+    fn ldpc_css_bp_create(
+        css: *const ldpc_css_code,
+        probability: c_double,
+        max_iterations: usize,
+        out: *mut *mut ldpc_css_bp_decoder,
+    ) -> c_int;
+    fn ldpc_css_bp_mc_run(
+        dec: *mut ldpc_css_bp_decoder,
+        noise_probability: c_double,
+        seed: u64,
+        first_shot: u64,
+        n_shots: usize,
+        counters: *mut u64,
+    ) -> c_int;
+    fn ldpc_css_bp_destroy(dec: *mut ldpc_css_bp_decoder);
 }
 
 /// Status codes other than 0 become the panics the reference raises for the same
@@ -280,5 +311,48 @@ impl GpuFlipDecoder {
 impl Drop for GpuFlipDecoder {
     fn drop(&mut self) {
         unsafe { ldpc_flip_destroy(self.handle) }
+    }
+}
+
+/// The loop of examples/css_decoding.rs:14-21 (sample a depolarizing error, syndrome, decode X and Z
+/// parts with BP, test `has_stabilizer`) as one device run.  The code's own stabilizers and logicals
+/// are handed over as they are (`CssCode::{x,z}_stabs_binary`, `{x,z}_logicals_binary`), so the failure
+/// test is the crate's.  counters: [shots, failures, detected, undetected, iterations, capped, xfail, zfail].
+pub struct GpuCssMonteCarlo {
+    css: *mut ldpc_css_code,
+    handle: *mut ldpc_css_bp_decoder,
+}
+
+unsafe impl Send for GpuCssMonteCarlo {}
+unsafe impl Sync for GpuCssMonteCarlo {}
+
+impl GpuCssMonteCarlo {
+    pub fn new(code: &ldpc::codes::CssCode, probability: Probability, num_iterations: usize) -> Self {
+        let hx = Code::from_matrix(code.x_stabs_binary());
+        let hz = Code::from_matrix(code.z_stabs_binary());
+        let lx = Code::from_matrix(code.x_logicals_binary());
+        let lz = Code::from_matrix(code.z_logicals_binary());
+        let mut css = std::ptr::null_mut();
+        check(unsafe { ldpc_css_create_with_logicals(hx.0, hz.0, lx.0, lz.0, &mut css) });
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ldpc_css_bp_create(css, probability.value(), num_iterations, &mut handle) });
+        Self { css, handle }
+    }
+
+    pub fn run(&self, noise: Probability, seed: u64, first_shot: u64, n_shots: usize) -> [u64; LDPC_COUNTERS] {
+        let mut counters = [0u64; LDPC_COUNTERS];
+        check(unsafe {
+            ldpc_css_bp_mc_run(self.handle, noise.value(), seed, first_shot, n_shots, counters.as_mut_ptr())
+        });
+        counters
+    }
+}
+
+impl Drop for GpuCssMonteCarlo {
+    fn drop(&mut self) {
+        unsafe {
+            ldpc_css_bp_destroy(self.handle);
+            ldpc_css_destroy(self.css);
+        }
     }
 }
