@@ -163,3 +163,28 @@ def test_bp_full_size_properties():
     a = dec.mc_run(p, SEED, 0, 12345)
     b = dec.mc_run(p, SEED, 12345, shots - 12345)
     assert ((a + b) == cnt).all()
+
+
+def test_bp_rare_failures_are_the_oracles():
+    # C2 at p = 0.02 fails about once in 10^5 shots.  The shots the device run flags as failures are decoded by
+    # the oracle one by one: each must fail there too (same correction or at least a non-zero residual with the
+    # same stop), and a sample of unflagged shots must succeed.
+    n, m, shots, p = 10000, 5000, 1 << 19, 0.02
+    code = LinearCode.random_regular_code(n, m, 3, 6, seed=1)
+    oc = oracle_code(code)
+    dec = BpDecoder(code, p, 100)
+    flags = dev_u8((shots,))
+    cnt = dec.mc_run(p, 1, 0, shots, flags)
+    failing = np.nonzero(flags.cpu().numpy())[0]
+    assert len(failing) == cnt[CNT_FAILURES] and 0 < len(failing) < 50
+    for i in failing:
+        e = orc.sample_bsc_words(1, int(i), p, n)
+        out, _ = oc.bp_decode_words(p, 100, e)
+        assert out.any(), i
+    rng = np.random.default_rng(0)
+    for i in rng.choice(shots, 40, replace=False):
+        if i in failing:
+            continue
+        e = orc.sample_bsc_words(1, int(i), p, n)
+        out, _ = oc.bp_decode_words(p, 100, e)
+        assert not out.any(), i
