@@ -237,6 +237,22 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
                        uint64_t first_shot, size_t n_shots, uint64_t counters[LDPC_COUNTERS]);
 void ldpc_css_bp_destroy(ldpc_css_bp_decoder *dec);
 
+/* ---- one process, several GPUs ------------------------------------------- */
+/* The Monte-Carlo runs above, sharded over `n_devices` GPUs from ONE process (the route for a host that
+ * is not launched one process per GPU, e.g. a Rust binary using the crate): one host thread per device,
+ * each with its own decoder, decodes the global shot range [first_shot + n_shots*k/n, first_shot +
+ * n_shots*(k+1)/n); the counters are summed on the host.  Shots are independent (examples/css_decoding.rs:14-21
+ * carries only the failure count between iterations) and the noise is keyed by the global shot index, so the
+ * result does not depend on n_devices.  devices = NULL means 0 .. n_devices-1; a device may be named twice. */
+int ldpc_flip_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability,
+                           uint64_t seed, uint64_t first_shot, size_t n_shots, uint64_t counters[LDPC_COUNTERS]);
+int ldpc_bp_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability,
+                         size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                         uint64_t counters[LDPC_COUNTERS]);
+int ldpc_css_bp_mc_run_multi(const ldpc_css_code *css, int n_devices, const int *devices, double probability,
+                             size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                             uint64_t counters[LDPC_COUNTERS]);
+
 #ifdef __cplusplus
 }
 #endif

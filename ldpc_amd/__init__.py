@@ -124,6 +124,9 @@ def lib():
         "ldpc_css_bp_correction_for": (i, [vp, vp, sz, vp, sz, vp, C.POINTER(sz), vp, C.POINTER(sz)]),
         "ldpc_css_bp_mc_run": (i, [vp, dbl, u64, u64, sz, vp]),
         "ldpc_css_bp_destroy": (None, [vp]),
+        "ldpc_flip_mc_run_multi": (i, [vp, i, vp, dbl, u64, u64, sz, vp]),
+        "ldpc_bp_mc_run_multi": (i, [vp, i, vp, dbl, sz, u64, u64, sz, vp]),
+        "ldpc_css_bp_mc_run_multi": (i, [vp, i, vp, dbl, sz, u64, u64, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -696,3 +699,21 @@ class CssDecoder:
         _check(lib().ldpc_css_bp_mc_run(self._h, _pval(noise_probability), int(seed), int(first_shot), int(n_shots),
                                         cnt.ctypes.data_as(C.c_void_p)))
         return cnt
+
+
+def mc_run_multi(code, devices, probability, seed, first_shot, n_shots, decoder="flip", max_iterations=100):
+    """One process, several GPUs (ldpc_*_mc_run_multi): `code` is a LinearCode (decoder "flip" or "bp") or a CssCode
+    (decoder "css"); `devices` a list of device ordinals (a device may appear twice).  Returns the summed counters."""
+    dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+    out = np.zeros(N_COUNTERS, dtype=np.uint64)
+    po = out.ctypes.data_as(C.c_void_p)
+    if decoder == "flip":
+        _check(lib().ldpc_flip_mc_run_multi(code._h, len(devices), dev, _pval(probability), int(seed), int(first_shot),
+                                            int(n_shots), po))
+    elif decoder == "bp":
+        _check(lib().ldpc_bp_mc_run_multi(code._h, len(devices), dev, _pval(probability), int(max_iterations), int(seed),
+                                          int(first_shot), int(n_shots), po))
+    else:
+        _check(lib().ldpc_css_bp_mc_run_multi(code._h, len(devices), dev, _pval(probability), int(max_iterations),
+                                              int(seed), int(first_shot), int(n_shots), po))
+    return out

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1242,6 +1244,81 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
 }
 
 void ldpc_css_bp_destroy(ldpc_css_bp_decoder *dec) { delete dec; }
+
+// ---- one process, several GPUs ---------------------------------------------
+extern "C++" {
+namespace {
+// Runs `shard(k, first, count, counters)` on one host thread per device (device and stream are per-thread state)
+// and sums the counters.  The first failing shard's status and message are reported.
+template <class Shard>
+int run_multi(int n_devices, const int *devices, uint64_t first_shot, size_t n_shots, uint64_t *counters, Shard shard)
+{
+    if (n_devices < 1 || !counters) return fail(LDPC_ERR_BAD_ARG, "n_devices must be at least 1");
+    std::vector<std::array<uint64_t, LDPC_COUNTERS>> part((size_t)n_devices);
+    std::vector<int> status((size_t)n_devices, LDPC_OK);
+    std::vector<std::string> message((size_t)n_devices);
+    std::vector<std::thread> threads;
+    for (int k = 0; k < n_devices; k++)
+        threads.emplace_back([&, k]() {
+            part[(size_t)k].fill(0);
+            const size_t lo = (size_t)((unsigned __int128)n_shots * (unsigned)k / (unsigned)n_devices),
+                         hi = (size_t)((unsigned __int128)n_shots * (unsigned)(k + 1) / (unsigned)n_devices);
+            int st = ldpc_set_device(devices ? devices[k] : k);
+            if (!st) st = shard(first_shot + lo, hi - lo, part[(size_t)k].data());
+            status[(size_t)k] = st;
+            if (st) message[(size_t)k] = ldpc_last_error();
+        });
+    for (auto &t : threads) t.join();
+    for (int i = 0; i < LDPC_COUNTERS; i++) counters[i] = 0;
+    for (int k = 0; k < n_devices; k++) {
+        if (status[(size_t)k]) return fail(status[(size_t)k], "device shard " + std::to_string(k) + ": " + message[(size_t)k]);
+        for (int i = 0; i < LDPC_COUNTERS; i++) counters[i] += part[(size_t)k][(size_t)i];
+    }
+    return LDPC_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int ldpc_flip_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability, uint64_t seed,
+                           uint64_t first_shot, size_t n_shots, uint64_t counters[LDPC_COUNTERS])
+{
+    if (!code) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
+        ldpc_flip_decoder *dec = nullptr;
+        int st = ldpc_flip_create(code, &dec);
+        if (!st) st = ldpc_flip_mc_run(dec, probability, seed, first, count, c, nullptr, nullptr, nullptr);
+        ldpc_flip_destroy(dec);
+        return st;
+    });
+}
+
+int ldpc_bp_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability,
+                         size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                         uint64_t counters[LDPC_COUNTERS])
+{
+    if (!code) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
+        ldpc_bp_decoder *dec = nullptr;
+        int st = ldpc_bp_create(code, probability, max_iterations, &dec);
+        if (!st) st = ldpc_bp_mc_run(dec, probability, seed, first, count, c, nullptr);
+        ldpc_bp_destroy(dec);
+        return st;
+    });
+}
+
+int ldpc_css_bp_mc_run_multi(const ldpc_css_code *css, int n_devices, const int *devices, double probability,
+                             size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                             uint64_t counters[LDPC_COUNTERS])
+{
+    if (!css) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
+        ldpc_css_bp_decoder *dec = nullptr;
+        int st = ldpc_css_bp_create(css, probability, max_iterations, &dec);
+        if (!st) st = ldpc_css_bp_mc_run(dec, probability, seed, first, count, c);
+        ldpc_css_bp_destroy(dec);
+        return st;
+    });
+}
 
 // Not part of the drop-in ABI (absent from include/ldpc_hip.h): lets the tests measure the
 // accuracy of the BP kernel's tanh(x/2) / log1p routines (csrc/bp_math.hpp) on device arrays.

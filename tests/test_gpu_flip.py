@@ -113,3 +113,20 @@ def test_flip_full_size_properties():
     assert ((a + b) == cnt).all()
     mean_w = float(sum(bin(int(x)).count("1") for x in host_u64(de[:64]).ravel())) / 64
     assert 150 < mean_w < 250
+
+
+def test_single_process_multi_device_runs_sum_to_the_single_run():
+    """ldpc_*_mc_run_multi: one host thread per device, shots sharded by global index, counters summed on the host.
+    On a one-GPU box the device list names GPU 0 several times (the shards then run concurrently on it)."""
+    from ldpc_amd import BpDecoder, CssCode, CssDecoder, mc_run_multi
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+    ref = FlipDecoder(code).mc_run(0.04, 5, 100, 30001)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        assert (mc_run_multi(code, devs, 0.04, 5, 100, 30001, "flip") == ref).all()
+    ref = BpDecoder(code, 0.09, 20).mc_run(0.09, 5, 100, 5000)
+    assert (mc_run_multi(code, [0, 0], 0.09, 5, 100, 5000, "bp", 20) == ref).all()
+    css = CssCode.shor_code()
+    ref = CssDecoder(css, 0.05, 30).mc_run(0.05, 5, 0, 4000)
+    assert (mc_run_multi(css, [0, 0], 0.05, 5, 0, 4000, "css", 30) == ref).all()
+    with pytest.raises(Exception):
+        mc_run_multi(code, [99], 0.04, 5, 0, 10, "flip")
