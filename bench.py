@@ -216,7 +216,7 @@ def main():
             },
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             cb, _ = cpu_baseline(code)
             line["cpu_baseline"] = cb
         if not args.no_bp and world == 1:
