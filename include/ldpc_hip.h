@@ -123,6 +123,15 @@ int ldpc_code_generator_matrix(const ldpc_code *code, size_t *row_ptr, size_t *c
 int ldpc_code_dimension(const ldpc_code *code, size_t *out);
 int ldpc_code_minimal_distance(const ldpc_code *code, size_t *distance, int *found);
 int ldpc_code_has_same_codespace(const ldpc_code *code, const ldpc_code *other, int *out);
+/* LinearCode::as_json (mod.rs:468-471) and its inverse, serde_json::from_str::<LinearCode> (derive mod.rs:51):
+ * {"parity_check_matrix":M,"generator_matrix":M,"bit_adjacencies":M}.  PARITY UNPINNED: M is the serde form of the
+ * un-vendored sparse-bin-mat crate's SparseBinMat, assumed {"row_ranges":[..],"column_indices":[..],
+ * "number_of_columns":n}; the reference holds no sample of it.  as_json writes a NUL-terminated string of
+ * *needed bytes (NUL included) when capacity allows, else returns LDPC_ERR_CAPACITY with *needed set (call with
+ * capacity 0 to size the buffer).  from_json needs parity_check_matrix; the other members, when present, must agree
+ * with it (transpose; orthogonal, as from_both_matrices mod.rs:59-72 demands) or the call returns LDPC_ERR_BAD_ARG. */
+int ldpc_code_as_json(const ldpc_code *code, char *buf, size_t capacity, size_t *needed);
+int ldpc_code_from_json(const char *text, size_t len, ldpc_code **out);
 void ldpc_code_destroy(ldpc_code *code);
 
 /* ---- noise (src/noise) ------------------------------------------------- */
@@ -219,6 +228,11 @@ int ldpc_css_erasure_num_bad_errors(const ldpc_css_code *css, size_t len, const 
                                     size_t *bad_x, size_t *bad_z);
 int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, const size_t *erasure,
                                           size_t n_erased, double *out);
+/* serde form of CssCode (derive css/mod.rs:24-28; Css<T> css.rs:7-11): {"stabilizers":{"x":M,"z":M},
+ * "logicals":{"x":M,"z":M}}, M as for ldpc_code_as_json (PARITY UNPINNED likewise).  from_json checks equal lengths
+ * and Hx * Hz^T == 0 (css/mod.rs:36-42: LDPC_ERR_CSS) and keeps the logicals the text holds. */
+int ldpc_css_as_json(const ldpc_css_code *css, char *buf, size_t capacity, size_t *needed);
+int ldpc_css_from_json(const char *text, size_t len, ldpc_css_code **out);
 void ldpc_css_destroy(ldpc_css_code *css);
 
 /* ---- CssDecoder<BpDecoder> (decoders/css.rs, examples/css_decoding.rs) -- */

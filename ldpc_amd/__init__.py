@@ -88,6 +88,10 @@ def lib():
         "ldpc_code_dimension": (i, [vp, C.POINTER(sz)]),
         "ldpc_code_minimal_distance": (i, [vp, C.POINTER(sz), C.POINTER(i)]),
         "ldpc_code_has_same_codespace": (i, [vp, vp, C.POINTER(i)]),
+        "ldpc_code_as_json": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "ldpc_code_from_json": (i, [C.c_char_p, sz, pp]),
+        "ldpc_css_as_json": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "ldpc_css_from_json": (i, [C.c_char_p, sz, pp]),
         "ldpc_code_destroy": (None, [vp]),
         "ldpc_erasure_sample_error_of_length": (i, [dbl, sz, u64, u64, vp, C.POINTER(sz)]),
         "ldpc_bsc_sample_error_of_length": (i, [dbl, sz, u64, u64, vp, C.POINTER(sz)]),
@@ -205,6 +209,16 @@ def _pval(p):
 
 def _rows_from_csr(ptr, idx):
     return [[int(x) for x in idx[ptr[r]: ptr[r + 1]]] for r in range(len(ptr) - 1)]
+
+
+def _json_text(fn, handle):
+    need = C.c_size_t(0)
+    fn(handle, None, 0, C.byref(need))          # sizing call: LDPC_ERR_CAPACITY with *needed set
+    if need.value == 0:
+        _check(fn(handle, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(fn(handle, C.cast(buf, C.c_void_p), need.value, C.byref(need)))
+    return buf.value.decode()
 
 
 class LinearCode:
@@ -330,6 +344,18 @@ class LinearCode:
         r = C.c_int(0)
         _check(lib().ldpc_code_has_same_codespace(self._h, other._h, C.byref(r)))
         return bool(r.value)
+
+    def as_json(self):
+        """linear_code/mod.rs:468-471 (layout of the inner matrices: see include/ldpc_hip.h, parity unpinned)"""
+        return _json_text(lib().ldpc_code_as_json, self._h)
+
+    @staticmethod
+    def from_json(text):
+        """serde_json::from_str::<LinearCode> (derive linear_code/mod.rs:51)"""
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        _check(lib().ldpc_code_from_json(raw, len(raw), C.byref(h)))
+        return LinearCode(h)
 
     # hot path ---------------------------------------------------------------
     def syndrome_of(self, positions, length=None):
@@ -579,6 +605,17 @@ class CssCode:
     def hypergraph_product(first_code, second_code):
         h = C.c_void_p()
         _check(lib().ldpc_css_hypergraph_product(first_code._h, second_code._h, C.byref(h)))
+        return CssCode(h)
+
+    def as_json(self):
+        """serde form of CssCode (derive codes/css/mod.rs:24-28)"""
+        return _json_text(lib().ldpc_css_as_json, self._h)
+
+    @staticmethod
+    def from_json(text):
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        _check(lib().ldpc_css_from_json(raw, len(raw), C.byref(h)))
         return CssCode(h)
 
     def len(self):

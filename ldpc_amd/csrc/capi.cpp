@@ -17,6 +17,7 @@
 
 #include "../../include/ldpc_hip.h"
 #include "host_codes.hpp"
+#include "host_json.hpp"
 #include "kernels.hpp"
 
 using namespace ldpc;
@@ -675,6 +676,31 @@ int ldpc_code_has_same_codespace(const ldpc_code *code, const ldpc_code *other, 
     return LDPC_OK;
 }
 
+static int give_text(const std::string &s, char *buf, size_t capacity, size_t *needed)
+{
+    *needed = s.size() + 1;
+    if (capacity < s.size() + 1 || !buf)
+        return fail(LDPC_ERR_CAPACITY, "json text needs " + std::to_string(s.size() + 1) + " bytes");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return LDPC_OK;
+}
+
+int ldpc_code_as_json(const ldpc_code *code, char *buf, size_t capacity, size_t *needed)
+{
+    if (!code || !needed) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    return give_text(linear_code_to_json(code->host), buf, capacity, needed);
+}
+
+int ldpc_code_from_json(const char *text, size_t len, ldpc_code **out)
+{
+    if (!text || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    LinearCode c;
+    std::string err;
+    if (!linear_code_from_json(text, len, c, err)) return fail(LDPC_ERR_BAD_ARG, err);
+    *out = new_code(std::move(c));
+    return LDPC_OK;
+}
+
 int ldpc_code_edges(const ldpc_code *code, size_t *bits, size_t *checks)
 {
     if (!code || ((!bits || !checks) && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
@@ -1159,6 +1185,30 @@ int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, 
     int st = ldpc_css_erasure_num_bad_errors(css, len, erasure, n_erased, &bx, &bz);
     if (st) return st;
     *out = std::ldexp(1.0, -(int)(bx + bz));   // css_erasure.rs:60-64
+    return LDPC_OK;
+}
+
+int ldpc_css_as_json(const ldpc_css_code *css, char *buf, size_t capacity, size_t *needed)
+{
+    if (!css || !needed) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    CssCode c;
+    c.hx = css->m[0].host;
+    c.hz = css->m[1].host;
+    c.lx = css->m[2].host;
+    c.lz = css->m[3].host;
+    return give_text(css_code_to_json(c), buf, capacity, needed);
+}
+
+int ldpc_css_from_json(const char *text, size_t len, ldpc_css_code **out)
+{
+    if (!text || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    CssCode c;
+    std::string err;
+    if (!css_code_from_json(text, len, c, err))
+        return fail(err.find("orthogonal") != std::string::npos || err.find("lengths") != std::string::npos ? LDPC_ERR_CSS
+                                                                                                           : LDPC_ERR_BAD_ARG,
+                    err);
+    *out = new_css(c);
     return LDPC_OK;
 }
 

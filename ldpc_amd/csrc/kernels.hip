@@ -485,7 +485,7 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
                 wave_order();
                 // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check
                 // (four records per trip: their row loads are in flight together)
-                constexpr uint32_t P2 = 4;
+                constexpr uint32_t P2 = 8;
                 for (uint32_t t0 = lane; t0 < (total << kshift); t0 += 64 * P2) {
                     NbRec<DVP> r[P2];
 #pragma unroll
