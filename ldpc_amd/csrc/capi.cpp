@@ -140,13 +140,23 @@ struct ldpc_code {
     LinearCode host;
     mutable std::mutex mu;
     mutable bool uploaded = false;
+    mutable int device = -1;   // the GPU that holds the graph (and the owning decoder's buffers)
     mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge;
     mutable DeviceGraph dg{};
 
     int ensure_device() const
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (uploaded) return LDPC_OK;
+        int current = 0;
+        HIP_TRY(hipGetDevice(&current));
+        if (uploaded) {
+            // a kernel launched on another GPU would dereference this GPU's pointers
+            if (current != device)
+                return fail(LDPC_ERR_BAD_ARG, "this handle's buffers live on device " + std::to_string(device) +
+                                                  ", the calling thread's current device is " + std::to_string(current) +
+                                                  ": create one handle per device");
+            return LDPC_OK;
+        }
         const SparseBinMat &h = host.h, &t = host.ht;
         // slot of bit_adjacencies -> edge index in check-major order
         std::vector<uint32_t> tedge(t.nnz());
@@ -176,6 +186,7 @@ struct ldpc_code {
         dg.t_ptr = d_tptr.as<uint32_t>();
         dg.t_idx = d_tidx.as<uint32_t>();
         dg.t_edge = d_tedge.as<uint32_t>();
+        device = current;
         uploaded = true;
         return LDPC_OK;
     }
@@ -410,8 +421,14 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     groups = std::max<uint64_t>(groups, 1);
     // Streamed form (one grid-wide kernel per phase, all CUs on every group) when memory, not the shot count,
     // leaves the persistent kernel with fewer workgroups than half the CUs: C5, 3 GB of messages per group.
+    // ... and when the call itself is small: up to 256 groups of work (one trait-level call is a single shot) leave
+    // the persistent kernel one workgroup per group and most CUs idle, each iteration paying the latency of a whole
+    // pass over the graph; the streamed kernels put every CU on those groups.  Measured (scripts/bp_small_batch.py):
+    // one shot at C2 10.5 -> 0.7 ms, 64 groups 17 -> 5.4 ms, even at 512 groups; below E = 3000 a round's launches
+    // cost more than the persistent iteration and nothing is gained.
     const uint64_t by_memory = budget / std::max<size_t>(per_group, 1);
-    bool stream = by_memory < 128;
+    const uint64_t work_groups = (r.n_shots + 63) / 64;
+    bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256);
     if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) {   // A/B and test aid
         if (!std::strcmp(e, "stream")) stream = true;
         else if (!std::strcmp(e, "persistent")) stream = false;

@@ -1447,8 +1447,8 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, 
         }
 }
 
-// one wave per group: counters and per-shot outputs of the slots that stop, slots freed; count_alive: add the
-// slots still active to *s.alive (the host's loop condition)
+// one wave per group: counters and per-shot outputs of the slots that stop, slots freed; alive: add the
+// slots still active (plus one while the shot queue holds shots) to *alive, the host's loop condition
 __global__ __launch_bounds__(64) void bps_ctl_harvest(BpArgs a, BpsState s, uint32_t g0, int only_fresh, unsigned long long *alive)
 {
     const size_t grp = bps_grp(s, g0 + blockIdx.x);
@@ -1483,6 +1483,9 @@ __global__ __launch_bounds__(64) void bps_ctl_harvest(BpArgs a, BpsState s, uint
         if (lane == 0) s.act[grp] = act;
     }
     if (alive && lane == 0 && act) atomicAdd(alive, (unsigned long long)__builtin_popcountll(act));
+    // shots still queued keep the host's loop going even when every slot has just stopped (fresh shots with a zero
+    // syndrome stop in the round that loads them)
+    if (alive && lane == 0 && blockIdx.x == 0 && *a.queue < a.n_shots) atomicAdd(alive, 1ull);
 }
 
 // (group, part): update_checks
@@ -1846,6 +1849,8 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
         tail = true;
     }
+    // a call whose shots were all loaded by the first control has nothing left to refill either: short control
+    if (!resume && a.n_shots <= 64ull * groups) tail = true;
     const uint64_t max_rounds = 2 * (((a.n_shots + 64ull * groups - 1) / (64ull * groups) + 1) * ((uint64_t)a.max_iter + 2) + 2);
     uint64_t rounds = 0;
     if (alive[0] && alive[1]) {   // skew the sets: set 0 starts half an iteration early

@@ -14,6 +14,17 @@ from tests.gpu_util import dev_f64, dev_u32, dev_u64, dev_u8, host_u32, host_u64
 pytestmark = pytest.mark.gpu
 
 SEED = 2024
+
+
+@pytest.fixture(autouse=True, params=["default", "persistent"])
+def bp_form(request, monkeypatch):
+    """Small calls on codes with E >= 3000 take the streamed kernels by default (capi.cpp run_bp); every test here
+    runs both with that choice and with the persistent kernel forced, each against the oracle."""
+    if request.param == "persistent":
+        monkeypatch.setenv("LDPC_HIP_BP_PATH", "persistent")
+    return request.param
+
+
 LLR_RTOL = 1e-5
 DECISION_MATCH = 0.9999
 

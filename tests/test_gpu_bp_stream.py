@@ -12,11 +12,17 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(monkeypatch, fn):
+    """persistent kernel, streamed form with every shot loaded at once (short control), and streamed form held to
+    two groups so that slots are refilled from the shot queue (the C5 regime); the last two must agree."""
     out = {}
     for path in ("persistent", "stream"):
         monkeypatch.setenv("LDPC_HIP_BP_PATH", path)
         out[path] = fn()
+    monkeypatch.setenv("LDPC_HIP_BP_GROUPS", "2")
+    refilled = fn()
+    monkeypatch.delenv("LDPC_HIP_BP_GROUPS")
     monkeypatch.delenv("LDPC_HIP_BP_PATH")
+    assert _same(out["stream"], refilled)
     return out["persistent"], out["stream"]
 
 
@@ -113,10 +119,12 @@ def test_tail_handoff_changes_nothing(monkeypatch):
         return host_u64(do), host_u32(di), cnt, flags.cpu().numpy()
 
     out = {}
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "persistent")   # (a call this small would take the streamed form)
     for h in ("0", "16", "1"):
         monkeypatch.setenv("LDPC_HIP_BP_HANDOFF", h)
         out[h] = run()
     monkeypatch.delenv("LDPC_HIP_BP_HANDOFF")
+    monkeypatch.delenv("LDPC_HIP_BP_PATH")
     assert (out["0"][1] == 80).sum() > 10          # the case has stragglers at the cap
     assert _same(out["0"], out["16"]) and _same(out["0"], out["1"])
 
