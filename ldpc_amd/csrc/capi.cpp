@@ -143,6 +143,10 @@ struct ldpc_code {
     mutable int device = -1;   // the GPU that holds the graph (and the owning decoder's buffers)
     mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge;
     mutable DeviceGraph dg{};
+    // staging for the single-vector entry points (kept across calls: a trait-level call is one shot, and an
+    // allocation and a free per call would cost more than its kernel); io_mu is held for the whole call
+    mutable std::mutex io_mu;
+    mutable DeviceBuffer io_in, io_out;
 
     int ensure_device() const
     {
@@ -200,6 +204,8 @@ struct ldpc_flip_decoder {
     ldpc_code code;
     std::mutex mu;
     DeviceBuffer counters, nb, o_scratch, flip_log;
+    std::mutex io_mu;               // single-vector staging, as in ldpc_code
+    DeviceBuffer io_in, io_out;
     NbTable nbt{};
     int path = 0;   // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel
 };
@@ -210,6 +216,8 @@ struct ldpc_bp_decoder {
     uint32_t max_iter = 0;
     std::mutex mu;
     DeviceBuffer counters, workspace, stream_state;
+    std::mutex io_mu;               // single-vector staging, as in ldpc_code
+    DeviceBuffer io_in, io_out;
     int reg_dc = 0, reg_dv = 0;   // common check / bit degree when the code is regular, else 0
 };
 
@@ -237,11 +245,6 @@ void export_csr(const SparseBinMat &m, size_t *row_ptr, size_t *col_idx)
     for (size_t i = 0; i < m.ptr.size(); i++) row_ptr[i] = m.ptr[i];
     for (size_t i = 0; i < m.idx.size(); i++) col_idx[i] = m.idx[i];
 }
-
-// --- device scratch for the single-vector entry points -----------------------
-struct Scratch {
-    DeviceBuffer in, out, aux, aux2;
-};
 
 int read_counters(DeviceBuffer &d, uint64_t *out)
 {
@@ -752,11 +755,14 @@ int ldpc_code_syndrome_of(const ldpc_code *code, size_t len, const size_t *posit
     if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
     size_t m = code->host.num_checks();
     std::vector<uint64_t> in = pack(positions, n_positions, len), out(std::max<size_t>(words_for(m), 1), 0);
-    DeviceBuffer din, dout;
+    int st = code->ensure_device();   // (before the staging buffers: they must live on the handle's device)
+    if (st) return st;
+    std::lock_guard<std::mutex> io(code->io_mu);
+    DeviceBuffer &din = code->io_in, &dout = code->io_out;
     HIP_TRY(din.reserve(in.size() * 8));
     HIP_TRY(dout.reserve(out.size() * 8));
     HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
-    int st = ldpc_code_syndrome_batch(code, 1, din.as<uint64_t>(), dout.as<uint64_t>());
+    st = ldpc_code_syndrome_batch(code, 1, din.as<uint64_t>(), dout.as<uint64_t>());
     if (st) return st;
     HIP_TRY(hipMemcpyAsync(out.data(), dout.p, out.size() * 8, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -893,11 +899,14 @@ int ldpc_flip_decode(ldpc_flip_decoder *dec, size_t len, const size_t *positions
                                                   std::to_string(dec->code.host.len()));
     if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
     std::vector<uint64_t> in = pack(positions, n_positions, len), out(in.size(), 0);
-    DeviceBuffer din, dout;
+    int st = dec->code.ensure_device();
+    if (st) return st;
+    std::lock_guard<std::mutex> io(dec->io_mu);
+    DeviceBuffer &din = dec->io_in, &dout = dec->io_out;
     HIP_TRY(din.reserve(in.size() * 8));
     HIP_TRY(dout.reserve(in.size() * 8));
     HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
-    int st = ldpc_flip_decode_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr, nullptr);
+    st = ldpc_flip_decode_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr, nullptr);
     if (st) return st;
     HIP_TRY(hipMemcpyAsync(out.data(), dout.p, in.size() * 8, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -983,11 +992,14 @@ static int bp_single(ldpc_bp_decoder *dec, bool is_syndrome, size_t len, const s
     if (!valid_positions(positions, n_positions, len)) return fail(LDPC_ERR_BAD_ARG, "positions are not sorted, unique and in range");
     if (n && !out_positions) return fail(LDPC_ERR_BAD_ARG, "null argument");
     std::vector<uint64_t> in = pack(positions, n_positions, len), out(std::max<size_t>(words_for(n), 1), 0);
-    DeviceBuffer din, dout;
+    int st = dec->code.ensure_device();
+    if (st) return st;
+    std::lock_guard<std::mutex> io(dec->io_mu);
+    DeviceBuffer &din = dec->io_in, &dout = dec->io_out;
     HIP_TRY(din.reserve(in.size() * 8));
     HIP_TRY(dout.reserve(out.size() * 8));
     HIP_TRY(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, g_stream));
-    int st = is_syndrome
+    st = is_syndrome
                  ? ldpc_bp_correction_for_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr, nullptr)
                  : ldpc_bp_decode_batch(dec, 1, din.as<uint64_t>(), dout.as<uint64_t>(), nullptr);
     if (st) return st;
