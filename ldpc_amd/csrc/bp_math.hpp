@@ -27,19 +27,19 @@ __device__ inline double bp_div_core(double a, double b)
     return fma(fma(-b, q, a), r, q);
 }
 
-// true when |v| < 2^-511 (zero and denormals included) or v is NaN / infinite
-__device__ inline bool bp_exponent_out_of_band(double v)
-{
-    return (uint32_t)((__double2hiint(v) & 0x7ff00000) - 0x20000000) >= 0x5ff00000u - 0x20000000u;
-}
+// true when |v| < 2^-511 (zero and denormals included).  NaN is NOT flagged: bp_div_core propagates a NaN operand
+// as the IEEE division does, and the non-converging shots of a degenerate quantum code carry NaN messages through
+// most of their 100 iterations (inf - inf in update_bits once tanh has saturated) -- flagged, they sent nearly
+// every wave of the CSS workload through the slow division.
+__device__ inline bool bp_exponent_below_band(double v) { return (uint32_t)(__double2hiint(v) & 0x7ff00000) < 0x20000000u; }
 
-// prod / t of update_checks (belief_propagation.rs:158): |prod| <= |t| <= 1 (prod has t as a factor).
-// Fast path when t is in the normal band; any lane outside it (t == 0 gives the reference's 0/0 = NaN,
-// NaN inputs, denormal t) sends the wave through the IEEE division.
+// prod / t of update_checks (belief_propagation.rs:158): |prod| <= |t| <= 1 (prod has t as a factor), or NaN.
+// Fast path when t is in the normal band or NaN; a lane below it (t == 0 gives the reference's 0/0 = NaN,
+// denormal t) sends the wave through the IEEE division.
 __device__ inline double bp_div_prod(double prod, double t)
 {
     double q = bp_div_core(prod, t);
-    if (__builtin_expect(__ballot(bp_exponent_out_of_band(t)) != 0, 0)) q = prod / t;
+    if (__builtin_expect(__ballot(bp_exponent_below_band(t)) != 0, 0)) q = prod / t;
     return q;
 }
 
@@ -132,8 +132,9 @@ __device__ inline double bp_log1p_main(double x)
     return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + (dk * ln2_lo + c))) - f);
 }
 
-// arguments bp_log1p_main does not serve: NaN, -inf, +-0, +inf (class mask 0x267) and x <= -1
-__device__ inline bool bp_log1p_is_special(double x) { return __builtin_amdgcn_class(x, 0x267) || x <= -1.0; }
+// arguments bp_log1p_main does not serve: -inf, +-0, +inf (class mask 0x264) and x <= -1.  (A NaN comes out of
+// bp_log1p_main as a NaN -- through c -- and is not flagged, for the reason given at bp_exponent_below_band.)
+__device__ inline bool bp_log1p_is_special(double x) { return __builtin_amdgcn_class(x, 0x264) || x <= -1.0; }
 
 __device__ inline double bp_log1p_fix(double x, double res)
 {
@@ -155,17 +156,14 @@ __device__ inline double bp_log1p(double x)
 // f64::atanh of the reference's toolchain, 0.5 * ln_1p(2x / (1 - x)) (belief_propagation.rs:159), for
 // |x| <= 1 or NaN (x is a product of tanh values divided by one of its factors): 1 - x is 0 (x == 1:
 // the quotient is 2/0 = +inf), or lies in [2^-53, 2], where the fast division applies.
-// argument of ln_1p in the reference's atanh: 2x / (1 - x).  The fast quotient is wrong only for
-// x == 1 (1 - x == 0: the reference gets 2/0 = +inf, the fast path NaN): bp_atanh_arg_is_rare / _slow.
-__device__ inline double bp_atanh_arg(double x) { return bp_div_core(2.0 * x, 1.0 - x); }
-__device__ inline bool bp_atanh_arg_is_rare(double x) { return x == 1.0; }
-__device__ inline double bp_atanh_arg_slow(double x) { return (2.0 * x) / (1.0 - x); }
-
-__device__ inline double bp_ref_atanh(double x)
+// bp_atanh_arg: argument of ln_1p, 2x / (1 - x).  x == 1 (every other tanh of the check saturated, the usual state
+// of a shot that does not converge) is patched by a select rather than a branch to the IEEE division.
+__device__ inline double bp_atanh_arg(double x)
 {
-    double q = bp_atanh_arg(x);
-    if (__builtin_expect(__ballot(bp_atanh_arg_is_rare(x)) != 0, 0)) q = bp_atanh_arg_slow(x);
-    return 0.5 * bp_log1p(q);
+    const double q = bp_div_core(2.0 * x, 1.0 - x);
+    return x == 1.0 ? __builtin_huge_val() : q;
 }
+
+__device__ inline double bp_ref_atanh(double x) { return 0.5 * bp_log1p(bp_atanh_arg(x)); }
 
 }  // namespace ldpc

@@ -497,7 +497,10 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         // (a streamed round costs about 0.15 ms of launches and one host sync: below E = 3000 a lone group's
         // iteration is cheaper than that and the tail stays in the persistent kernel; measured at C1 and C3)
         const bool forced = std::getenv("LDPC_HIP_BP_HANDOFF") != nullptr;
-        if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 3000)) handoff = 0xFFFFFFFFu;
+        // ... unless many groups are in play: then the stragglers of all of them are packed into few groups
+        // (bps_compact), which the persistent kernel cannot do (C3, 5 % of the shots run all 100 iterations:
+        // 272 -> see DESIGN.md)
+        if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 3000 && groups < 64)) handoff = 0xFFFFFFFFu;
         a.handoff_iter = handoff;
         if (handoff != 0xFFFFFFFFu) {
             HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));

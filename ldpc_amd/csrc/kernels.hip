@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -695,9 +696,9 @@ template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uin
 #pragma unroll
     for (int j = 0; j < DC; j++) prod *= t[j];
     // 2 atanh(prod / t_j): the common-case arithmetic of a batch first, the rare operands patched in blocks a
-    // wave seldom enters.  |prod| <= |t_j| <= 1, so prod inside the normal band puts every t_j inside it (and
-    // a NaN or zero t_j makes prod NaN or zero): one test per check.
-    const bool odd_prod = bp_exponent_out_of_band(prod);
+    // wave seldom enters.  |prod| <= |t_j| <= 1, so prod inside the normal band puts every t_j inside it (a zero
+    // t_j makes prod zero; a NaN goes through the fast division as through the IEEE one): one test per check.
+    const bool odd_prod = bp_exponent_below_band(prod);
 #pragma unroll
     for (int h0 = 0; h0 < DC; h0 += HB) {
         double y[HB], w[HB], l[HB];
@@ -713,13 +714,13 @@ template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uin
 #pragma unroll
         for (int j = 0; j < HB; j++)
             if (h0 + j < DC) {
-                w[j] = bp_atanh_arg(y[j]);
-                rare |= bp_atanh_arg_is_rare(y[j]);
+                w[j] = bp_div_core(2.0 * y[j], 1.0 - y[j]);   // bp_atanh_arg without its select
+                rare |= y[j] == 1.0;
             }
-        if (__builtin_expect(__ballot(rare) != 0, 0)) {
+        if (__builtin_expect(__ballot(rare) != 0, 0)) {        // 2 / 0 = +inf (bp_math.hpp, bp_atanh_arg)
 #pragma unroll
             for (int j = 0; j < HB; j++)
-                if (h0 + j < DC) w[j] = bp_atanh_arg_slow(y[j]);
+                if (h0 + j < DC) w[j] = y[j] == 1.0 ? __builtin_huge_val() : w[j];
         }
 #pragma unroll
         for (int j = 0; j < HB; j++)
@@ -1585,6 +1586,68 @@ __global__ __launch_bounds__(64) void bps_ctl_advance(BpsState s, uint32_t g0)
     }
 }
 
+// (destination group, part): tail compaction.  Once nothing is left to refill, the shots still running are
+// spread thinly over many groups, and a group costs a full pass over its message rows however few of its 64
+// slots are active.  The host lists moves (moves[j * 64 + slot] = source group * 64 + source slot, or
+// 0xFFFFFFFF) from the active slots of the groups that are given up into free slots of the groups that are kept;
+// this kernel copies a moved shot's state: its column of the bit-message rows (the check messages too when
+// posteriors are wanted: at an iteration boundary nothing else reads them), of the error / decision words, its
+// bit of the bit-sliced decision and syndrome rows, its shot index and iteration count.  Sources are active
+// slots, destinations free ones: no move reads what another writes.  Lanes compute nothing across slots, so
+// a shot's results do not depend on where it sits.
+__global__ __launch_bounds__(BPS_THREADS) void bps_compact(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, const uint32_t *moves,
+                                                           int with_chk)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t j = blockIdx.x / parts, part = blockIdx.x % parts;
+    const size_t dgrp = bps_grp(s, j);
+    const uint32_t mv = moves[(size_t)j * 64 + lane];
+    const bool recv = mv != 0xFFFFFFFFu;
+    const uint64_t recvmask = __ballot(recv);
+    if (!recvmask) return;
+    const size_t sgrp = recv ? (size_t)(mv >> 6) : dgrp;
+    const uint32_t sslot = recv ? (mv & 63u) : lane;
+    const BpsGroup D = bps_group(g, a, dgrp), S = bps_group(g, a, sgrp);
+    const uint32_t n = g.n, m = g.m, E = g.E, Wn = (n + 63) / 64;
+    const uint32_t nwv = parts * BPS_WAVES, w0 = part * BPS_WAVES + wv;
+    for (uint32_t e = w0; e < E; e += nwv)
+        if (recv) {
+            D.bitsm[(size_t)e * 64 + lane] = S.bitsm[(size_t)e * 64 + sslot];
+            if (with_chk) D.chkm[(size_t)e * 64 + lane] = S.chkm[(size_t)e * 64 + sslot];
+        }
+    for (uint32_t w = w0; w < Wn; w += nwv)
+        if (recv) {
+            D.ew[(size_t)w * 64 + lane] = S.ew[(size_t)w * 64 + sslot];
+            D.dw[(size_t)w * 64 + lane] = S.dw[(size_t)w * 64 + sslot];
+        }
+    // bit-sliced rows, 64 at a time: lane i ends up with the row of bit (check) b0 + i
+    for (uint32_t b0 = w0 * 64; b0 < n; b0 += nwv * 64) {
+        const uint32_t cnt = n - b0 < 64u ? n - b0 : 64u;
+        uint64_t row = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const bool bit = recv && ((S.dsl[b0 + i] >> sslot) & 1ull);
+            const uint64_t mask = __ballot(bit);
+            if (lane == i) row = mask;
+        }
+        if (lane < cnt) D.dsl[b0 + lane] = (D.dsl[b0 + lane] & ~recvmask) | row;
+    }
+    for (uint32_t c0 = w0 * 64; c0 < m; c0 += nwv * 64) {
+        const uint32_t cnt = m - c0 < 64u ? m - c0 : 64u;
+        uint64_t row = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const bool bit = recv && ((S.ssl[c0 + i] >> sslot) & 1ull);
+            const uint64_t mask = __ballot(bit);
+            if (lane == i) row = mask;
+        }
+        if (lane < cnt) D.ssl[c0 + lane] = (D.ssl[c0 + lane] & ~recvmask) | row;
+    }
+    if (part == 0 && wv == 0 && recv) {
+        s.iter[dgrp * 64 + lane] = s.iter[mv];
+        s.myi[dgrp * 64 + lane] = s.myi[mv];
+        s.flags[dgrp * 64 + lane] = 0;   // (the harvest ORs into it; the slot's last shot may have left bits)
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1756,7 +1819,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
     return hipGetLastError();
 }
 
-size_t bp_stream_state_bytes(uint32_t groups) { return (size_t)groups * (5 * 8 + 64 * (4 + 8 + 4) + 4) + 64; }
+size_t bp_stream_state_bytes(uint32_t groups) { return (size_t)groups * (5 * 8 + 64 * (4 + 8 + 4 + 4) + 4) + 64; }
 
 // Runs the streamed BP to completion on `st`.  `state` = bp_stream_state_bytes(groups) bytes of device memory.
 BpsState bp_stream_state_at(void *state, uint32_t groups)
@@ -1771,7 +1834,8 @@ BpsState bp_stream_state_at(void *state, uint32_t groups)
     s.myi = (uint64_t *)p; p += (size_t)groups * 64 * 8;
     s.iter = (uint32_t *)p; p += (size_t)groups * 64 * 4;
     s.flags = (uint32_t *)p; p += (size_t)groups * 64 * 4;
-    s.gmap_store = (uint32_t *)p;
+    s.gmap_store = (uint32_t *)p; p += (size_t)groups * 4;
+    s.moves = (uint32_t *)p;
     s.gmap = nullptr;
     return s;
 }
@@ -1831,6 +1895,56 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
         else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
     };
+    // Tail compaction (bps_compact): when the shots left fill at most half the slots of the groups in play, move
+    // them into the first ceil(alive / 64) of those groups and drop the rest.  Called after a control (the stream is
+    // idle, the state at an iteration boundary); a round costs a pass over every group in play, a compaction less
+    // than one such pass.
+    std::vector<uint32_t> glist;   // host copy of the group list behind s.gmap (empty: identity)
+    uint64_t compactions = 0;
+    auto compact = [&]() -> hipError_t {
+        const uint32_t cur = setn[0];
+        hipError_t err;
+        std::vector<uint64_t> act(groups), fr(groups);
+        if ((err = hipMemcpyAsync(act.data(), s.act, (size_t)groups * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
+        if ((err = hipMemcpyAsync(fr.data(), s.fresh, (size_t)groups * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
+        if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;
+        auto phys = [&](uint32_t i) { return glist.empty() ? i : glist[i]; };
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < cur; i++) {
+            if (fr[phys(i)] & act[phys(i)]) return hipSuccess;   // a fresh slot has no messages yet: wait a round
+            total += (uint64_t)__builtin_popcountll(act[phys(i)]);
+        }
+        const uint32_t keep = (uint32_t)((total + 63) / 64);
+        if (keep == 0 || keep >= cur) return hipSuccess;
+        std::vector<uint32_t> src, mv((size_t)keep * 64, 0xFFFFFFFFu);
+        for (uint32_t i = keep; i < cur; i++) {
+            for (uint64_t mleft = act[phys(i)]; mleft; mleft &= mleft - 1)
+                src.push_back(phys(i) * 64u + (uint32_t)__builtin_ctzll(mleft));
+            act[phys(i)] = 0;
+        }
+        for (uint32_t jd = 0; jd < keep && !src.empty(); jd++)
+            for (uint32_t slot = 0; slot < 64 && !src.empty(); slot++)
+                if (!((act[phys(jd)] >> slot) & 1ull)) {
+                    mv[(size_t)jd * 64 + slot] = src.back();
+                    src.pop_back();
+                    act[phys(jd)] |= 1ull << slot;
+                    fr[phys(jd)] &= ~(1ull << slot);   // (a shot harvested in its first round leaves the bit set)
+                }
+        if (!src.empty()) return hipErrorLaunchFailure;   // cannot happen: keep * 64 >= total
+        if ((err = hipMemcpyAsync(s.moves, mv.data(), mv.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
+        uint32_t cparts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / keep);
+        cparts = std::min<uint32_t>(cparts, std::max<uint32_t>(1, (g.E + BPS_WAVES - 1) / BPS_WAVES));
+        hipLaunchKernelGGL(bps_compact, dim3(keep * cparts), blk, 0, st, g, a, s, cparts, (const uint32_t *)s.moves, a.post_out ? 1 : 0);
+        if ((err = hipMemcpyAsync(s.act, act.data(), (size_t)groups * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
+        if ((err = hipMemcpyAsync(s.fresh, fr.data(), (size_t)groups * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
+        if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;   // (the host vectors go out of scope)
+        setn[0] = keep;
+        parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / keep);
+        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+        compactions++;
+        return hipGetLastError();
+    };
+    const bool may_compact = !skew && std::getenv("LDPC_HIP_BP_NO_COMPACT") == nullptr;   // (A/B and test aid)
     for (int t = 0; t < 2; t++)
         if (setn[t] && (e = control(t)) != hipSuccess) return e;
     if (resume && alive[0]) {
@@ -1847,7 +1961,9 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         setn[0] = (uint32_t)list.size();
         parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / setn[0]);
         parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+        glist = list;
         tail = true;
+        if (may_compact && setn[0] > 1 && alive[0] <= 32ull * setn[0] && (e = compact()) != hipSuccess) return e;
     }
     // a call whose shots were all loaded by the first control has nothing left to refill either: short control
     if (!resume && a.n_shots <= 64ull * groups) tail = true;
@@ -1871,10 +1987,12 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
             hipLaunchKernelGGL(bps_ctl_advance, dim3(setn[b]), one, 0, st, s, set0[b]);
             if ((e = control(b)) != hipSuccess) return e;
             wants_checks[b] = true;
+            if (tail && may_compact && setn[0] > 1 && alive[0] && alive[0] <= 32ull * setn[0] && (e = compact()) != hipSuccess) return e;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (rounds_out) *rounds_out = rounds;
+    if (std::getenv("LDPC_HIP_DEBUG") && compactions) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu tail compactions\n", (unsigned long long)compactions);
     return hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ struct BpsState {
     uint32_t *iter, *flags;             // [groups][64]
     const uint32_t *gmap;               // when set: kernels work on the groups gmap[0..) instead of 0.. (tail)
     uint32_t *gmap_store;               // [groups] room for that list
+    uint32_t *moves;                    // [groups][64] move table of the tail compaction (bps_compact)
 };
 
 struct BpArgs {

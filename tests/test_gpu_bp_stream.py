@@ -129,6 +129,40 @@ def test_tail_handoff_changes_nothing(monkeypatch):
     assert _same(out["0"], out["16"]) and _same(out["0"], out["1"])
 
 
+def test_tail_compaction_changes_nothing(monkeypatch, capfd):
+    """Once nothing is left to refill, the streamed form packs the shots still running into fewer groups
+    (bps_compact: message columns, words, bit-sliced rows and slot state move to free slots).  Same corrections,
+    iteration counts, posteriors, failure flags and counters as without it, on a point where most shots straggle."""
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+    p, shots = 0.15, 2500
+    oc = oracle_code(code)
+    syn = np.stack([oc.syndrome_words(orc.sample_bsc_words(78, i, p, 1200)) for i in range(shots)])
+
+    def run():
+        dec = BpDecoder(code, p, 60)
+        dc_, di, dp = dev_u64((shots, nwords(1200))), dev_u32((shots,)), dev_f64((shots, 1200))
+        dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di, dp)
+        flags = dev_u8((shots,))
+        cnt = dec.mc_run(p, 78, 0, shots, flags)
+        return host_u64(dc_), host_u32(di), dp.cpu().numpy(), cnt, flags.cpu().numpy()
+
+    monkeypatch.setenv("LDPC_HIP_DEBUG", "1")
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "stream")
+    capfd.readouterr()
+    packed = run()
+    assert "tail compactions" in capfd.readouterr().err
+    monkeypatch.setenv("LDPC_HIP_BP_NO_COMPACT", "1")
+    plain = run()
+    assert "tail compactions" not in capfd.readouterr().err
+    monkeypatch.delenv("LDPC_HIP_BP_NO_COMPACT")
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "persistent")
+    monkeypatch.setenv("LDPC_HIP_BP_HANDOFF", "4")
+    handed = run()
+    assert "tail compactions" in capfd.readouterr().err
+    assert (plain[1] == 60).sum() > 20 and plain[4].sum() > 20        # stragglers at the cap, failures flagged
+    assert _same(plain, packed) and _same(plain, handed)
+
+
 def test_css_counters_same_on_every_path(monkeypatch):
     """CSS Monte-Carlo (X and Z halves, logical failure test): persistent kernel without hand-off, with hand-off,
     and the streamed form give the same counters."""
