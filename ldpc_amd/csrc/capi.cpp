@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -427,11 +428,12 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // ... and when the call itself is small: up to 256 groups of work (one trait-level call is a single shot) leave
     // the persistent kernel one workgroup per group and most CUs idle, each iteration paying the latency of a whole
     // pass over the graph; the streamed kernels put every CU on those groups.  Measured (scripts/bp_small_batch.py):
-    // one shot at C2 10.5 -> 0.7 ms, 64 groups 17 -> 5.4 ms, even at 512 groups; below E = 3000 a round's launches
-    // cost more than the persistent iteration and nothing is gained.
+    // one shot at C2 10.5 -> 0.34 ms, 64 groups 17 -> 4.8 ms, even at 512 groups; between E = 200 and 3000 the
+    // streamed form still wins up to 128 groups (E = 2100: one shot 0.65 -> 0.28 ms), below E = 200 a round's
+    // launches cost more than the persistent iteration.
     const uint64_t by_memory = budget / std::max<size_t>(per_group, 1);
     const uint64_t work_groups = (r.n_shots + 63) / 64;
-    bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256);
+    bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256) || (g.E >= 200 && work_groups <= 128);
     if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) {   // A/B and test aid
         if (!std::strcmp(e, "stream")) stream = true;
         else if (!std::strcmp(e, "persistent")) stream = false;
@@ -494,13 +496,11 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         // has drained are finished by the streamed form, the whole chip on the few groups that hold them
         uint32_t handoff = 16;
         if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) handoff = (uint32_t)std::strtoul(e, nullptr, 10);   // 0 = off
-        // (a streamed round costs about 0.15 ms of launches and one host sync: below E = 3000 a lone group's
-        // iteration is cheaper than that and the tail stays in the persistent kernel; measured at C1 and C3)
+        // (the streamed tail packs the stragglers of all groups into few (bps_compact), which the persistent
+        // kernel cannot do, and a streamed iteration of a small tail costs about 0.05 ms of launches: below
+        // E = 200 a lone group's persistent iteration is cheaper than that; scripts/bp_small_batch.py)
         const bool forced = std::getenv("LDPC_HIP_BP_HANDOFF") != nullptr;
-        // ... unless many groups are in play: then the stragglers of all of them are packed into few groups
-        // (bps_compact), which the persistent kernel cannot do (C3, 5 % of the shots run all 100 iterations:
-        // 272 -> see DESIGN.md)
-        if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 3000 && groups < 64)) handoff = 0xFFFFFFFFu;
+        if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 200)) handoff = 0xFFFFFFFFu;
         a.handoff_iter = handoff;
         if (handoff != 0xFFFFFFFFu) {
             HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
@@ -508,15 +508,20 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
             a.handoff = bp_stream_state_at(dec->stream_state.p, (uint32_t)groups);
             a.handoff_flag = dec->counters.as<unsigned long long>() + LDPC_COUNTERS + 1;
         }
+        const auto t0 = std::chrono::steady_clock::now();
         HIP_TRY(launch_bp(g, a, (uint32_t)groups, waves, dec->reg_dc, dec->reg_dv, g_stream));
         if (handoff != 0xFFFFFFFFu) {
             unsigned long long flag = 0;
             HIP_TRY(hipMemcpyAsync(&flag, a.handoff_flag, 8, hipMemcpyDeviceToHost, g_stream));
             HIP_TRY(hipStreamSynchronize(g_stream));
             if (flag) {
+                const auto t1 = std::chrono::steady_clock::now();
                 uint64_t rounds = 0;
                 HIP_TRY(bp_stream_run(g, a, dec->stream_state.p, (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds, true));
-                if (std::getenv("LDPC_HIP_DEBUG")) std::fprintf(stderr, "[ldpc_hip] bp tail hand-off: %llu streamed rounds\n", (unsigned long long)rounds);
+                if (std::getenv("LDPC_HIP_DEBUG"))
+                    std::fprintf(stderr, "[ldpc_hip] bp tail hand-off: persistent kernel %.2f ms, then %llu streamed rounds in %.2f ms\n",
+                                 std::chrono::duration<double, std::milli>(t1 - t0).count(), (unsigned long long)rounds,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
             }
         }
     }

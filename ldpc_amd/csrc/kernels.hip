@@ -1540,7 +1540,8 @@ __device__ inline void bps_checks_body(const DeviceGraph &g, const BpArgs &a, co
 
 // (group, part): update_bits + hard decisions
 template <int DV>
-__device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, const BpsState &s, size_t grp, uint32_t part, uint32_t parts)
+__device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, const BpsState &s, size_t grp, uint32_t part, uint32_t parts,
+                                     uint32_t split)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t actmask = s.act[grp];
@@ -1548,8 +1549,9 @@ __device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, cons
     const BpsGroup G = bps_group(g, a, grp);
     const bool active = (actmask >> lane) & 1ull;
     const uint32_t Wn = (g.n + 63) / 64;
-    for (uint32_t chunk = part * BPS_WAVES + wv; chunk < Wn; chunk += parts * BPS_WAVES)
-        bp_bits_chunk<DV>(g, chunk, 1, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
+    // (split: pieces per 64-bit chunk, 1 when the groups in play fill the chip with whole chunks; see bp_stream_run)
+    for (uint32_t item = part * BPS_WAVES + wv; item < Wn * split; item += parts * BPS_WAVES)
+        bp_bits_chunk<DV>(g, item, split, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
 }
 
 // One half-step of the streamed form: update_checks on the groups [gc0, gc0 + gcn) and update_bits on the
@@ -1557,7 +1559,7 @@ __device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, cons
 // is bound by f64 issue, the bit update by HBM, and two group sets half an iteration apart keep both busy.
 template <int DC, int DV>
 __global__ __launch_bounds__(BPS_THREADS, 4) void bps_iterate(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t gc0,
-                                                              uint32_t gcn, uint32_t gb0, uint32_t gbn)
+                                                              uint32_t gcn, uint32_t gb0, uint32_t gbn, uint32_t split)
 {
     const uint32_t nc = gcn * parts, nb = gbn * parts, mn = nc < nb ? nc : nb;
     bool checks;
@@ -1570,7 +1572,7 @@ __global__ __launch_bounds__(BPS_THREADS, 4) void bps_iterate(DeviceGraph g, BpA
         idx = blockIdx.x - mn;
     }
     if (checks) bps_checks_body<DC>(g, a, s, bps_grp(s, gc0 + idx / parts), idx % parts, parts);
-    else bps_bits_body<DV>(g, a, s, bps_grp(s, gb0 + idx / parts), idx % parts, parts);
+    else bps_bits_body<DV>(g, a, s, bps_grp(s, gb0 + idx / parts), idx % parts, parts, split);
 }
 
 // one wave per group: the iteration is over
@@ -1851,8 +1853,17 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t Wn = (g.n + 63) / 64;
-    uint32_t parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / groups);
-    parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+    // The bit update works a 64-bit chunk per wave, or half / a quarter of one when whole chunks would leave the
+    // chip's 16 waves per CU mostly empty (small codes, the few groups of a tail): a piece's edge rows are fetched
+    // one batch after the other, so the phase lasts as long as its longest piece however idle the chip is.
+    uint32_t parts = 1, bsplit = 1;
+    auto retile = [&](uint32_t in_play) {
+        const uint64_t chunks = (uint64_t)in_play * Wn, room = 16ull * (uint64_t)cus;
+        bsplit = chunks >= room ? 1u : 2 * chunks >= room ? 2u : 4u;
+        parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / in_play);
+        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn * bsplit + BPS_WAVES - 1) / BPS_WAVES));
+    };
+    retile(groups);
     const dim3 blk(BPS_THREADS), one(64);
     // two sets of groups half an iteration apart (see bps_iterate); a single group runs alone
     // Measured at C5: no gain from the skew (a check-update wave keeps its SIMD only 22 % busy, so the check update
@@ -1863,6 +1874,11 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     bool wants_checks[2] = {true, true};
     bool tail = false;   // resume mode after the first round: nothing can be refilled, short control
     // stop test, harvest, refill, set-up, stop test and harvest of the new shots (a zero syndrome stops at once)
+    // In the tail the host reads the alive count (one sync) only every `burst` iterations: rounds on shots that
+    // have stopped meanwhile do nothing (stopped slots are harvested once and leave the active mask; groups
+    // without active slots return at once), and a round of a small tail costs less than the sync.
+    uint32_t burst = 4, since_sync = 0;
+    if (const char *ev = std::getenv("LDPC_HIP_BP_TAIL_BURST")) burst = (uint32_t)std::max(1, std::atoi(ev));   // A/B aid
     auto control = [&](int t) -> hipError_t {
         const dim3 grid(setn[t] * parts), ctl(setn[t]);
         const uint32_t g0 = set0[t];
@@ -1884,16 +1900,18 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
             if ((err = hipMemsetAsync(s.alive + t, 0, 8, st)) != hipSuccess) return err;
             hipLaunchKernelGGL(bps_ctl_harvest, ctl, one, 0, st, a, s, g0, 1, s.alive + t);
         }
+        if (tail && ++since_sync < burst) return hipSuccess;   // alive[t] stays as last read (non-zero)
+        since_sync = 0;
         if ((err = hipMemcpyAsync(&alive[t], s.alive + t, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return err;
         return hipStreamSynchronize(st);
     };
     auto iterate = [&](int c, int b) {
         const uint32_t gc0 = c >= 0 ? set0[c] : 0, gcn = c >= 0 ? setn[c] : 0, gb0 = b >= 0 ? set0[b] : 0, gbn = b >= 0 ? setn[b] : 0;
         const dim3 grid((gcn + gbn) * parts);
-        if (dc == 6 && dv == 3) hipLaunchKernelGGL((bps_iterate<6, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
-        else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bps_iterate<4, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
-        else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
-        else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn);
+        if (dc == 6 && dv == 3) hipLaunchKernelGGL((bps_iterate<6, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bps_iterate<4, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
     };
     // Tail compaction (bps_compact): when the shots left fill at most half the slots of the groups in play, move
     // them into the first ceil(alive / 64) of those groups and drop the rest.  Called after a control (the stream is
@@ -1939,8 +1957,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         if ((err = hipMemcpyAsync(s.fresh, fr.data(), (size_t)groups * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
         if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;   // (the host vectors go out of scope)
         setn[0] = keep;
-        parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / keep);
-        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+        retile(keep);
         compactions++;
         return hipGetLastError();
     };
@@ -1959,15 +1976,14 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         if ((e = hipMemcpy(s.gmap_store, list.data(), list.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
         s.gmap = s.gmap_store;
         setn[0] = (uint32_t)list.size();
-        parts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / setn[0]);
-        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1, (Wn + BPS_WAVES - 1) / BPS_WAVES));
+        retile(setn[0]);
         glist = list;
         tail = true;
         if (may_compact && setn[0] > 1 && alive[0] <= 32ull * setn[0] && (e = compact()) != hipSuccess) return e;
     }
     // a call whose shots were all loaded by the first control has nothing left to refill either: short control
     if (!resume && a.n_shots <= 64ull * groups) tail = true;
-    const uint64_t max_rounds = 2 * (((a.n_shots + 64ull * groups - 1) / (64ull * groups) + 1) * ((uint64_t)a.max_iter + 2) + 2);
+    const uint64_t max_rounds = 2 * burst + 2 * (((a.n_shots + 64ull * groups - 1) / (64ull * groups) + 1) * ((uint64_t)a.max_iter + 2) + 2);
     uint64_t rounds = 0;
     if (alive[0] && alive[1]) {   // skew the sets: set 0 starts half an iteration early
         iterate(0, -1);
@@ -1987,7 +2003,9 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
             hipLaunchKernelGGL(bps_ctl_advance, dim3(setn[b]), one, 0, st, s, set0[b]);
             if ((e = control(b)) != hipSuccess) return e;
             wants_checks[b] = true;
-            if (tail && may_compact && setn[0] > 1 && alive[0] && alive[0] <= 32ull * setn[0] && (e = compact()) != hipSuccess) return e;
+            if (tail && since_sync == 0 && may_compact && setn[0] > 1 && alive[0] && alive[0] <= 32ull * setn[0] &&
+                (e = compact()) != hipSuccess)
+                return e;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
