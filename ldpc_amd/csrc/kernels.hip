@@ -1913,7 +1913,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
     };
-    // Tail compaction (bps_compact): when the shots left fill at most half the slots of the groups in play, move
+    // Tail compaction (bps_compact): when the shots left fill at most 3/4 of the slots of the groups in play, move
     // them into the first ceil(alive / 64) of those groups and drop the rest.  Called after a control (the stream is
     // idle, the state at an iteration boundary); a round costs a pass over every group in play, a compaction less
     // than one such pass.
@@ -1979,7 +1979,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         retile(setn[0]);
         glist = list;
         tail = true;
-        if (may_compact && setn[0] > 1 && alive[0] <= 32ull * setn[0] && (e = compact()) != hipSuccess) return e;
+        if (may_compact && setn[0] > 1 && alive[0] <= 48ull * setn[0] && (e = compact()) != hipSuccess) return e;
     }
     // a call whose shots were all loaded by the first control has nothing left to refill either: short control
     if (!resume && a.n_shots <= 64ull * groups) tail = true;
@@ -2003,7 +2003,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
             hipLaunchKernelGGL(bps_ctl_advance, dim3(setn[b]), one, 0, st, s, set0[b]);
             if ((e = control(b)) != hipSuccess) return e;
             wants_checks[b] = true;
-            if (tail && since_sync == 0 && may_compact && setn[0] > 1 && alive[0] && alive[0] <= 32ull * setn[0] &&
+            if (tail && since_sync == 0 && may_compact && setn[0] > 1 && alive[0] && alive[0] <= 48ull * setn[0] &&
                 (e = compact()) != hipSuccess)
                 return e;
         }
