@@ -1146,20 +1146,28 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
         if constexpr (DC > 0) {
             // software pipeline: the DC message rows of the wave's next check are in flight while the
             // tanh / log1p chains of the current one run
-            double xn[DC];
-            if (wv < m) {
+            // (DC >= 7: the second row of registers does not fit next to the batch temporaries; the row is loaded
+            // where it is used and the other waves of the SIMD cover the latency)
+            constexpr bool PF = DC < 7;
+            double xn[PF ? DC : 1];
+            if (PF && wv < m) {
 #pragma unroll
-                for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : bitsm[((size_t)wv * DC + j) * 64 + lane];
+                for (int j = 0; j < (PF ? DC : 0); j++) xn[j] = fresh ? t_prior : bitsm[((size_t)wv * DC + j) * 64 + lane];
             }
             for (uint32_t c = wv; c < m; c += NW) {
                 const size_t e0 = (size_t)c * DC;
                 const bool sbit = (ssl[c] >> lane) & 1ull;
                 double x[DC];
+                if constexpr (PF) {
 #pragma unroll
-                for (int j = 0; j < DC; j++) x[j] = xn[j];
-                if (c + NW < m) {
+                    for (int j = 0; j < DC; j++) x[j] = xn[j];
+                    if (c + NW < m) {
 #pragma unroll
-                    for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
+                        for (int j = 0; j < DC; j++) xn[j] = fresh ? t_prior : bitsm[((size_t)(c + NW) * DC + j) * 64 + lane];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DC; j++) x[j] = fresh ? t_prior : bitsm[(e0 + j) * 64 + lane];
                 }
                 double out[DC];
                 bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);

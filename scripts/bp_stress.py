@@ -19,7 +19,7 @@ for name, code in cases:
     for path in ("persistent", "stream"):
         os.environ["LDPC_HIP_BP_PATH"] = path
         for p, cap in ((0.01, 40), (0.06, 15)):
-            shots = 96
+            shots = int(sys.argv[1]) if len(sys.argv) > 1 else 96
             syn = np.zeros((shots, max(nwords(m), 1)), dtype=np.uint64)
             for i in range(shots):
                 syn[i, : nwords(m)] = oc.syndrome_words(orc.sample_bsc_words(4, i, p, n))
