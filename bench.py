@@ -75,7 +75,7 @@ def measured_traffic(shots_per_launch):
         return None
 
 
-def bp_line(code, shots=1 << 21):
+def bp_line(code, shots=1 << 23):
     """Secondary measurement: the f64 BP kernel on the same code and channel (Monte-Carlo mode,
     max 100 iterations).  Algorithmic bytes = 32*E per shot-iteration."""
     import ldpc_amd

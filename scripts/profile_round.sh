@@ -8,7 +8,7 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 FLIP="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bp"
-BP="python3 $ROOT/scripts/bp_one.py c2 2097152 0.02"
+BP="python3 $ROOT/scripts/bp_one.py c2 8388608 0.02"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/flip_stats" -o flip --output-format csv -- $FLIP > "$OUT/flip_stats.log" 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/bp_stats" -o bp --output-format csv -- $BP > "$OUT/bp_stats.log" 2>&1
 pass() {  # name, program, counters...

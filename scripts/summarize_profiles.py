@@ -55,7 +55,7 @@ flip = {
 }
 json.dump(flip, open(os.path.join(dst, "%s_flip_pmc.json" % tag), "w"), indent=1)
 
-# ---- bp (scripts/bp_one.py c2 2097152 0.02: a warm-up launch of 8192 shots, then the measured one)
+# ---- bp (scripts/bp_one.py c2 8388608 0.02: a warm-up launch of 8192 shots, then the measured one)
 rb, wb = traffic(counters("bp_rd", "bp_kernel"), counters("bp_wr", "bp_kernel"))
 ks = stats("bp_stats", "bp_kernel", "%s_bp_kernel_stats.csv" % tag)
 log = open(os.path.join(src, "bp_stats.log")).read()
@@ -64,7 +64,7 @@ kv = dict(zip(line[2::2], line[3::2]))
 iters, ms = int(kv["iters"]), float(kv["kernel_ms"])
 alg = iters * 32 * 30000
 bp = {
-    "command": "scripts/profile_round.sh: rocprofv3 --pmc <one counter group per pass> -- python3 scripts/bp_one.py c2 2097152 0.02",
+    "command": "scripts/profile_round.sh: rocprofv3 --pmc <one counter group per pass> -- python3 scripts/bp_one.py c2 8388608 0.02",
     "kernel": "bp_kernel<6,3>, 8 waves per 64-shot group, 512 groups", "shots": int(kv["shots"]), "shot_iterations": iters,
     "kernel_ms_hip_events_under_kernel_trace": ms,
     "algorithmic_bytes": alg, "algorithmic_GBs": alg / ms / 1e6,
