@@ -87,6 +87,14 @@ double ldpc_last_kernel_ms(void);
  * nullspace is host algebra off the decoding path and infeasible at n = 1e6). */
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx,
                      ldpc_code **out);
+/* LinearCode::from_generator_matrix (mod.rs:116-124): the parity checks are a basis of the nullspace of the
+ * generators (host elimination, small codes; the basis is this library's, see ldpc_code_generator_matrix).
+ * LinearCode::from_both_matrices (mod.rs:59-72): LDPC_ERR_BAD_ARG "matrices are non orthogonal" for the panic of
+ * :64-66; the generators are checked and not kept. */
+int ldpc_code_from_generator_matrix(size_t n_bits, size_t n_generators, const size_t *row_ptr, const size_t *col_idx,
+                                    ldpc_code **out);
+int ldpc_code_from_both_matrices(size_t n_bits, size_t n_generators, const size_t *g_row_ptr, const size_t *g_col_idx,
+                                 size_t n_checks, const size_t *h_row_ptr, const size_t *h_col_idx, ldpc_code **out);
 int ldpc_code_hamming(ldpc_code **out);                     /* mod.rs:161-167 */
 int ldpc_code_repetition(size_t length, ldpc_code **out);   /* mod.rs:139-143 */
 /* LinearCode::random_regular_code()...sample_with (mod.rs:202-204, random.rs:56-76).

@@ -88,6 +88,8 @@ def lib():
         "ldpc_code_dimension": (i, [vp, C.POINTER(sz)]),
         "ldpc_code_minimal_distance": (i, [vp, C.POINTER(sz), C.POINTER(i)]),
         "ldpc_code_has_same_codespace": (i, [vp, vp, C.POINTER(i)]),
+        "ldpc_code_from_generator_matrix": (i, [sz, sz, vp, vp, pp]),
+        "ldpc_code_from_both_matrices": (i, [sz, sz, vp, vp, sz, vp, vp, pp]),
         "ldpc_code_as_json": (i, [vp, vp, sz, C.POINTER(sz)]),
         "ldpc_code_from_json": (i, [C.c_char_p, sz, pp]),
         "ldpc_css_as_json": (i, [vp, vp, sz, C.POINTER(sz)]),
@@ -253,6 +255,39 @@ class LinearCode:
         h = C.c_void_p()
         _check(lib().ldpc_code_create(int(num_bits), len(ptr) - 1, pptr, pidx, C.byref(h)))
         return LinearCode(h)
+
+    @staticmethod
+    def _csr(rows):
+        ptr = np.zeros(len(rows) + 1, dtype=np.uintp)
+        for r, row in enumerate(rows):
+            ptr[r + 1] = ptr[r] + len(row)
+        idx = np.array([c for row in rows for c in row], dtype=np.uintp)
+        return ptr, idx
+
+    @staticmethod
+    def from_generator_matrix(num_bits, rows):
+        """linear_code/mod.rs:116-124"""
+        ptr, idx = LinearCode._csr(rows)
+        h = C.c_void_p()
+        _check(lib().ldpc_code_from_generator_matrix(int(num_bits), len(rows), ptr.ctypes.data_as(C.c_void_p),
+                                                     idx.ctypes.data_as(C.c_void_p), C.byref(h)))
+        return LinearCode(h)
+
+    @staticmethod
+    def from_both_matrices(num_bits, generator_rows, parity_check_rows):
+        """linear_code/mod.rs:59-72 (raises where the reference panics)"""
+        gp, gi = LinearCode._csr(generator_rows)
+        hp, hi = LinearCode._csr(parity_check_rows)
+        h = C.c_void_p()
+        _check(lib().ldpc_code_from_both_matrices(int(num_bits), len(generator_rows), gp.ctypes.data_as(C.c_void_p),
+                                                  gi.ctypes.data_as(C.c_void_p), len(parity_check_rows),
+                                                  hp.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), C.byref(h)))
+        return LinearCode(h)
+
+    @staticmethod
+    def empty():
+        """linear_code/mod.rs:172-175: length 0, no checks"""
+        return LinearCode.from_parity_check_matrix(0, [])
 
     @staticmethod
     def hamming_code():

@@ -611,6 +611,53 @@ int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, cons
     return LDPC_OK;
 }
 
+// rows (row_ptr, col_idx) -> SparseBinMat with the checks of ldpc_code_create; 0 on success
+static int matrix_from_csr(size_t n_cols, size_t n_rows, const size_t *row_ptr, const size_t *col_idx, SparseBinMat &out)
+{
+    if (!row_ptr && n_rows) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (n_cols >= 0xFFFFFFFFull || n_rows >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "dimension exceeds 32 bits");
+    std::vector<std::vector<uint32_t>> rows(n_rows);
+    if (n_rows) {
+        if (row_ptr[0] != 0) return fail(LDPC_ERR_BAD_ARG, "row_ptr[0] must be 0");
+        if (row_ptr[n_rows] >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "too many edges");
+        if (row_ptr[n_rows] && !col_idx) return fail(LDPC_ERR_BAD_ARG, "null argument");
+        for (size_t r = 0; r < n_rows; r++) {
+            if (row_ptr[r + 1] < row_ptr[r]) return fail(LDPC_ERR_BAD_ARG, "row_ptr must be non-decreasing");
+            for (size_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+                if (col_idx[e] >= n_cols) return fail(LDPC_ERR_BAD_ARG, "column index out of bound");
+                rows[r].push_back((uint32_t)col_idx[e]);
+            }
+        }
+    }
+    std::string err;
+    if (!SparseBinMat::from_rows((uint32_t)n_cols, rows, out, err)) return fail(LDPC_ERR_BAD_ARG, err);
+    return LDPC_OK;
+}
+
+int ldpc_code_from_generator_matrix(size_t n_bits, size_t n_generators, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    SparseBinMat gmat;
+    int st = matrix_from_csr(n_bits, n_generators, row_ptr, col_idx, gmat);
+    if (st) return st;
+    *out = new_code(make_code(nullspace(gmat)));   // linear_code/mod.rs:116-124
+    return LDPC_OK;
+}
+
+int ldpc_code_from_both_matrices(size_t n_bits, size_t n_generators, const size_t *g_row_ptr, const size_t *g_col_idx, size_t n_checks,
+                                 const size_t *h_row_ptr, const size_t *h_col_idx, ldpc_code **out)
+{
+    if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    SparseBinMat gmat, h;
+    int st = matrix_from_csr(n_bits, n_generators, g_row_ptr, g_col_idx, gmat);
+    if (st) return st;
+    if ((st = matrix_from_csr(n_bits, n_checks, h_row_ptr, h_col_idx, h))) return st;
+    // linear_code/mod.rs:59-72 (both matrices are given n_bits columns here, so only the second panic can occur)
+    if (!h.product_is_zero(gmat)) return fail(LDPC_ERR_BAD_ARG, "matrices are non orthogonal");
+    *out = new_code(make_code(std::move(h)));
+    return LDPC_OK;
+}
+
 int ldpc_code_hamming(ldpc_code **out)
 {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");

@@ -6,6 +6,7 @@ import itertools
 import numpy as np
 import pytest
 
+import ldpc_amd as L
 from ldpc_amd import CssCode, CssErasureDecoder, LinearCode
 from oracle import oracle as orc
 
@@ -112,3 +113,24 @@ def test_css_erasure_against_numpy_ranks():
         assert dec.num_bad_z_errors(er) == bad("x_stabs_binary", "x_logicals_binary")
     with pytest.raises(Exception):
         dec.recovery_probability([n])          # out of range
+
+
+def test_from_generator_matrix_doc_test_and_from_both_matrices():
+    """linear_code/mod.rs:104-115 (3-bit repetition code from its generator), :59-72 (from_both_matrices and its
+    panic on non-orthogonal matrices), :169-175 (empty)"""
+    code = L.LinearCode.from_generator_matrix(3, [[0, 1, 2]])
+    assert code.len() == 3 and code.dimension() == 1 and code.minimal_distance() == 3
+    assert code.has_same_codespace(L.LinearCode.repetition_code(3))
+    ham = L.LinearCode.hamming_code()
+    gen = ham.generator_matrix()
+    both = L.LinearCode.from_both_matrices(7, gen, ham.parity_check_matrix())
+    assert both.parity_check_matrix() == ham.parity_check_matrix()
+    back = L.LinearCode.from_generator_matrix(7, gen)                      # H = nullspace(G): same codespace
+    assert back.has_same_codespace(ham) and ham.has_same_codespace(back) and back.dimension() == 4
+    with pytest.raises(L.LdpcError) as e:
+        L.LinearCode.from_both_matrices(7, [[0]], ham.parity_check_matrix())
+    assert "non orthogonal" in str(e.value)
+    with pytest.raises(L.LdpcError):
+        L.LinearCode.from_generator_matrix(3, [[0, 3]])                    # column out of range
+    empty = L.LinearCode.empty()
+    assert empty.len() == 0 and empty.num_checks() == 0 and empty.dimension() == 0
