@@ -227,7 +227,7 @@ struct ldpc_css_bp_decoder {
     ldpc_bp_decoder z;   // BpDecoder on Hz: decodes syndrome.z, corrects the x part
     ldpc_code lx, lz;
     std::mutex mu;
-    DeviceBuffer flags, counters;
+    DeviceBuffer flags, flags2, counters;
 };
 
 namespace {
@@ -386,6 +386,7 @@ struct BpRun {
     double *post_out = nullptr;
     uint8_t *failed_out = nullptr;
     const ldpc_code *logicals = nullptr;
+    uint32_t share = 1;   // this run has 1 / share of the GPU's workgroup slots (CSS halves side by side)
 };
 
 int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool time_it = true)
@@ -416,8 +417,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // only as many groups as are resident at once: a queued workgroup would find the shot queue drained
     uint64_t over = 1;
     if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) over = (uint64_t)std::max(1, std::atoi(e));   // A/B aid
-    uint64_t max_groups = std::min<uint64_t>(over * bp_resident_groups(waves, dec->reg_dc, dec->reg_dv),
-                                             budget / std::max<size_t>(per_group, 1));
+    uint64_t max_groups = std::min<uint64_t>(std::max<uint64_t>(over * bp_resident_groups(waves, dec->reg_dc, dec->reg_dv) / r.share, 1),
+                                             budget / std::max<size_t>(per_group, 1) / r.share);
     if (max_groups == 0)
         return fail(LDPC_ERR_CAPACITY, "bp decoder: one shot group needs " + std::to_string(per_group) +
                                            " bytes of message storage, more than the device can give");
@@ -1333,6 +1334,11 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
     GapTable gap = make_gap_table(noise_probability);
     const size_t chunk_max = (size_t)1 << 28;
     double ms_total = 0.0;
+    // Small runs (the streamed kernels: at most 128 groups of work) decode the two halves side by side, see below:
+    // 1000 shots of the 625-qubit code 13.7 -> 7.3 ms.  Large runs do not: two persistent kernels on two streams were
+    // seen to run one after the other, each on half of the workgroup slots (8.4e6 shots: 1.24 -> 1.65 s).
+    bool side_by_side = n_shots <= 128 * 64;
+    if (const char *e = std::getenv("LDPC_HIP_CSS_SIDE_BY_SIDE")) side_by_side = std::atoi(e) != 0;   // A/B and test aid
     for (size_t done = 0; done < n_shots;) {
         size_t chunk = std::min(chunk_max, n_shots - done);
         HIP_TRY(dec->flags.reserve(chunk));
@@ -1343,26 +1349,80 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
         r.seed = seed;
         r.first_shot = first_shot + done;
         r.n_shots = chunk;
-        r.failed_out = dec->flags.as<uint8_t>();
         r.gap = gap;
         // x part of the error: syndrome.z = Hz * e_x, decoded by the z decoder (BP on Hz);
         // the residual's x part must commute with the Z-type logicals (rows of lz)
-        r.source = SRC_DEPOL_X;
-        r.fail_bit = 1;
-        r.logicals = &dec->lz;
-        int st = run_bp(&dec->z, r, cx);
-        if (st) return st;
-        ms_total += g_last_ms;
+        BpRun rz = r;
+        rz.source = SRC_DEPOL_X;
+        rz.fail_bit = 1;
+        rz.logicals = &dec->lz;
+        rz.failed_out = dec->flags.as<uint8_t>();
         // z part: syndrome.x = Hx * e_z, decoded by the x decoder (BP on Hx), logicals lx
-        r.source = SRC_DEPOL_Z;
-        r.fail_bit = 2;
-        r.logicals = &dec->lx;
-        st = run_bp(&dec->x, r, cz);
-        if (st) return st;
-        ms_total += g_last_ms;
+        BpRun rx = r;
+        rx.source = SRC_DEPOL_Z;
+        rx.fail_bit = 2;
+        rx.logicals = &dec->lx;
+        rx.failed_out = dec->flags.as<uint8_t>();
+        const uint8_t *flags2 = nullptr;
+        if (side_by_side) {
+            // The halves are independent (decoders/css.rs:10-15): run them at once, the second from a host thread
+            // of its own, each on a stream of its own.  The launch-bound rounds of two small runs then interleave
+            // instead of following each other.  Each half ORs into its own flag bytes (a byte has no atomic OR).
+            HIP_TRY(dec->flags2.reserve(chunk));
+            HIP_TRY(hipMemsetAsync(dec->flags2.p, 0, chunk, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            rx.failed_out = dec->flags2.as<uint8_t>();
+            flags2 = dec->flags2.as<uint8_t>();
+            rz.share = rx.share = 2;
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            int st_x = LDPC_OK;
+            std::string err_x;
+            double ms_x = 0.0;
+            std::thread other([&]() {
+                hipStream_t sx = nullptr;
+                if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&sx, hipStreamNonBlocking) != hipSuccess) {
+                    st_x = LDPC_ERR_HIP;
+                    err_x = "could not create the second stream";
+                    return;
+                }
+                g_stream = sx;
+                st_x = run_bp(&dec->x, rx, cz);
+                if (st_x) err_x = g_error;
+                ms_x = g_last_ms;
+                (void)hipStreamSynchronize(sx);
+                (void)hipStreamDestroy(sx);
+            });
+            // (this half too runs on a stream of its own: the null stream would order itself against the other)
+            hipStream_t caller = g_stream, sz = nullptr;
+            int st = LDPC_OK;
+            if (hipStreamCreateWithFlags(&sz, hipStreamNonBlocking) != hipSuccess) {
+                sz = nullptr;
+                st = fail(LDPC_ERR_HIP, "could not create a stream");
+            } else {
+                g_stream = sz;
+                st = run_bp(&dec->z, rz, cx);
+                (void)hipStreamSynchronize(sz);
+                (void)hipStreamDestroy(sz);
+                g_stream = caller;
+            }
+            const double ms_z = g_last_ms;
+            other.join();
+            if (st) return st;
+            if (st_x) return fail(st_x, err_x);
+            ms_total += std::max(ms_z, ms_x);
+        } else {
+            int st = run_bp(&dec->z, rz, cx);
+            if (st) return st;
+            ms_total += g_last_ms;
+            st = run_bp(&dec->x, rx, cz);
+            if (st) return st;
+            ms_total += g_last_ms;
+        }
+        int st = 0;
         st = zero_counters(dec->counters);
         if (st) return st;
-        HIP_TRY(launch_count_flags(dec->flags.as<uint8_t>(), chunk, dec->counters.as<unsigned long long>(), g_stream));
+        HIP_TRY(launch_count_flags(dec->flags.as<uint8_t>(), flags2, chunk, dec->counters.as<unsigned long long>(), g_stream));
         st = read_counters(dec->counters, cf);
         if (st) return st;
         counters[LDPC_CNT_SHOTS] += chunk;

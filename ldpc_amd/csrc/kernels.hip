@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256) void bp_math_probe_kernel(int kind, uint64_t n
     }
 }
 
-__global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *flags, uint64_t n, unsigned long long *counters)
+__global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *flags, const uint8_t *flags2, uint64_t n,
+                                                          unsigned long long *counters)
 {
     uint64_t f = 0, x = 0, z = 0;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t v = flags[t];
+        if (flags2) v |= flags2[t];   // the two halves of a CSS run, when they ran side by side
         f += v != 0;
         x += v & 1;
         z += (v >> 1) & 1;
@@ -2029,10 +2031,11 @@ hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double
     return hipGetLastError();
 }
 
-hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st)
+hipError_t launch_count_flags(const uint8_t *d_flags, const uint8_t *d_flags2, uint64_t n, unsigned long long *d_counters,
+                              hipStream_t st)
 {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(count_flags_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, d_flags, n, d_counters);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(grid_for(n, 256 * 16, 2048)), dim3(256), 0, st, d_flags, d_flags2, n, d_counters);
     return hipGetLastError();
 }
 

@@ -127,6 +127,7 @@ BpsState bp_stream_state_at(void *state, uint32_t groups);
 // resume: the state already holds slots handed off by bp_kernel (no reset)
 hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uint32_t groups, int dc, int dv, hipStream_t st,
                          uint64_t *rounds_out, bool resume = false);
-hipError_t launch_count_flags(const uint8_t *d_flags, uint64_t n, unsigned long long *d_counters, hipStream_t st);
+hipError_t launch_count_flags(const uint8_t *d_flags, const uint8_t *d_flags2, uint64_t n, unsigned long long *d_counters,
+                              hipStream_t st);
 
 }  // namespace ldpc

@@ -73,3 +73,21 @@ def test_css_mc_split_invariance_and_shor():
     oc = {k: orc.Code(9, rows=v.parity_check_matrix()) for k, v in d.items()}
     ref = orc.mc_css_bp(oc["hx"], oc["hz"], oc["lx"], oc["lz"], 0.05, 30, 3, 0, 5000, nthreads=8)
     _close(total, ref, 5000)
+
+
+def test_css_halves_side_by_side_or_in_turn(monkeypatch):
+    """Small runs decode the X and Z halves at once (two host threads, two streams, separate flag bytes); large runs
+    one after the other.  Same counters either way, for a run of each kind and with the choice forced."""
+    css = _example_code()
+    for shots, p in ((3000, 0.03), (20000, 0.02)):
+        res = []
+        for side in (None, "0", "1"):
+            if side is None:
+                monkeypatch.delenv("LDPC_HIP_CSS_SIDE_BY_SIDE", raising=False)
+            else:
+                monkeypatch.setenv("LDPC_HIP_CSS_SIDE_BY_SIDE", side)
+            res.append(CssDecoder(css, p, 40).mc_run(p, 9, 17, shots))
+        monkeypatch.delenv("LDPC_HIP_CSS_SIDE_BY_SIDE", raising=False)
+        assert res[0][CNT_SHOTS] == shots and res[0][CNT_FAILURES] > 20
+        assert res[0][CNT_XFAIL] > 0 and res[0][CNT_ZFAIL] > 0
+        assert (res[0] == res[1]).all() and (res[0] == res[2]).all()
