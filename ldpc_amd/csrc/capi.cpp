@@ -228,6 +228,11 @@ struct ldpc_css_bp_decoder {
     ldpc_code lx, lz;
     std::mutex mu;
     DeviceBuffer flags, flags2, counters;
+    hipStream_t side_stream = nullptr;   // for the half that runs beside the caller's stream (single-call entry point)
+    ~ldpc_css_bp_decoder()
+    {
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+    }
 };
 
 namespace {
@@ -1318,10 +1323,30 @@ int ldpc_css_bp_correction_for(ldpc_css_bp_decoder *dec, const size_t *sx, size_
                                size_t *out_cx, size_t *out_n_cx, size_t *out_cz, size_t *out_n_cz)
 {
     if (!dec) return fail(LDPC_ERR_BAD_ARG, "null argument");
-    // decoders/css.rs:10-15: pair(x decoder, syndrome.x), pair(z decoder, syndrome.z), then swap_xz
-    int st = ldpc_bp_correction_for(&dec->x, dec->x.code.host.num_checks(), sx, n_sx, out_cz, out_n_cz);
+    // decoders/css.rs:10-15: pair(x decoder, syndrome.x), pair(z decoder, syndrome.z), then swap_xz.  The two
+    // decodes are independent and each is a handful of launch-bound rounds: the second runs from a host thread of
+    // its own on the decoder's second stream, so that the rounds interleave.
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(dec->mu);
+    if (!dec->side_stream) HIP_TRY(hipStreamCreateWithFlags(&dec->side_stream, hipStreamNonBlocking));
+    int st_z = LDPC_OK;
+    std::string err_z;
+    std::thread other([&]() {
+        if (hipSetDevice(dev) != hipSuccess) {
+            st_z = LDPC_ERR_HIP;
+            err_z = "hipSetDevice failed";
+            return;
+        }
+        g_stream = dec->side_stream;
+        st_z = ldpc_bp_correction_for(&dec->z, dec->z.code.host.num_checks(), sz, n_sz, out_cx, out_n_cx);
+        if (st_z) err_z = g_error;
+    });
+    const int st = ldpc_bp_correction_for(&dec->x, dec->x.code.host.num_checks(), sx, n_sx, out_cz, out_n_cz);
+    other.join();
     if (st) return st;
-    return ldpc_bp_correction_for(&dec->z, dec->z.code.host.num_checks(), sz, n_sz, out_cx, out_n_cx);
+    if (st_z) return fail(st_z, err_z);
+    return LDPC_OK;
 }
 
 int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint64_t seed, uint64_t first_shot,
