@@ -13,6 +13,8 @@
 #include <thread>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -36,6 +38,12 @@ int fail(int status, const std::string &msg)
     g_error = msg;
     return status;
 }
+
+// Nothing may unwind across the C ABI: every `int ldpc_*` entry point is a function-try-block ending in this.
+#define LDPC_CATCH                                                                                  \
+    catch (const std::bad_alloc &) { return fail(LDPC_ERR_CAPACITY, "out of host memory"); }       \
+    catch (const std::exception &e) { return fail(LDPC_ERR_BAD_ARG, std::string("exception: ") + e.what()); } \
+    catch (...) { return fail(LDPC_ERR_BAD_ARG, "unexpected exception"); }
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -567,7 +575,7 @@ extern "C" {
 const char *ldpc_last_error(void) { return g_error.c_str(); }
 
 int ldpc_device_count(int *count)
-{
+try {
     if (!count) return fail(LDPC_ERR_BAD_ARG, "null argument");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -578,24 +586,27 @@ int ldpc_device_count(int *count)
     *count = c;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_set_device(int device)
-{
+try {
     HIP_TRY(hipSetDevice(device));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_set_stream(void *hip_stream)
-{
+try {
     g_stream = (hipStream_t)hip_stream;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 double ldpc_last_kernel_ms(void) { return g_last_ms; }
 
 // ---- LinearCode -----------------------------------------------------------
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
-{
+try {
     if (!out || (!row_ptr && n_checks)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (n_bits >= 0xFFFFFFFFull || n_checks >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "dimension exceeds 32 bits");
     std::vector<std::vector<uint32_t>> rows(n_checks);
@@ -616,6 +627,7 @@ int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, cons
     *out = new_code(make_code(std::move(h)));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 // rows (row_ptr, col_idx) -> SparseBinMat with the checks of ldpc_code_create; 0 on success
 static int matrix_from_csr(size_t n_cols, size_t n_rows, const size_t *row_ptr, const size_t *col_idx, SparseBinMat &out)
@@ -641,7 +653,7 @@ static int matrix_from_csr(size_t n_cols, size_t n_rows, const size_t *row_ptr, 
 }
 
 int ldpc_code_from_generator_matrix(size_t n_bits, size_t n_generators, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     SparseBinMat gmat;
     int st = matrix_from_csr(n_bits, n_generators, row_ptr, col_idx, gmat);
@@ -649,10 +661,11 @@ int ldpc_code_from_generator_matrix(size_t n_bits, size_t n_generators, const si
     *out = new_code(make_code(nullspace(gmat)));   // linear_code/mod.rs:116-124
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_from_both_matrices(size_t n_bits, size_t n_generators, const size_t *g_row_ptr, const size_t *g_col_idx, size_t n_checks,
                                  const size_t *h_row_ptr, const size_t *h_col_idx, ldpc_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     SparseBinMat gmat, h;
     int st = matrix_from_csr(n_bits, n_generators, g_row_ptr, g_col_idx, gmat);
@@ -663,25 +676,28 @@ int ldpc_code_from_both_matrices(size_t n_bits, size_t n_generators, const size_
     *out = new_code(make_code(std::move(h)));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_hamming(ldpc_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     *out = new_code(hamming_code());
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_repetition(size_t length, ldpc_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (length == 0 || length >= 0xFFFFFFFFull) return fail(LDPC_ERR_BAD_ARG, "invalid repetition code length");
     *out = new_code(repetition_code((uint32_t)length));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_random_regular(size_t n_bits, size_t n_checks, size_t bit_degree, size_t check_degree, uint64_t seed,
                              ldpc_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     LinearCode c;
     if (n_bits >= 0xFFFFFFFFull || n_checks >= 0xFFFFFFFFull || bit_degree >= 0xFFFFFFFFull ||
@@ -694,35 +710,39 @@ int ldpc_code_random_regular(size_t n_bits, size_t n_checks, size_t bit_degree, 
     *out = new_code(std::move(c));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 size_t ldpc_code_len(const ldpc_code *code) { return code ? code->host.len() : 0; }
 size_t ldpc_code_num_checks(const ldpc_code *code) { return code ? code->host.num_checks() : 0; }
 size_t ldpc_code_num_edges(const ldpc_code *code) { return code ? code->host.h.nnz() : 0; }
 
 int ldpc_code_parity_check_matrix(const ldpc_code *code, size_t *row_ptr, size_t *col_idx)
-{
+try {
     if (!code || !row_ptr || (!col_idx && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
     export_csr(code->host.h, row_ptr, col_idx);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_bit_adjacencies(const ldpc_code *code, size_t *row_ptr, size_t *col_idx)
-{
+try {
     if (!code || !row_ptr || (!col_idx && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
     export_csr(code->host.ht, row_ptr, col_idx);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 // ---- host algebra (small codes) ---------------------------------------------
 int ldpc_code_num_generators(const ldpc_code *code, size_t *out)
-{
+try {
     if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     *out = code->host.len() - gf2_rank(code->host.h);   // rows of a nullspace basis
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_generator_matrix(const ldpc_code *code, size_t *row_ptr, size_t *col_idx, size_t col_idx_capacity)
-{
+try {
     if (!code || !row_ptr) return fail(LDPC_ERR_BAD_ARG, "null argument");
     const SparseBinMat gmat = nullspace(code->host.h);
     if (gmat.nnz() > col_idx_capacity || (!col_idx && gmat.nnz()))
@@ -731,15 +751,17 @@ int ldpc_code_generator_matrix(const ldpc_code *code, size_t *row_ptr, size_t *c
     export_csr(gmat, row_ptr, col_idx);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_dimension(const ldpc_code *code, size_t *out)
-{
+try {
     // generator_matrix.rank() (mod.rs:308-310); the rows of a nullspace basis are independent
     return ldpc_code_num_generators(code, out);
 }
+LDPC_CATCH
 
 int ldpc_code_minimal_distance(const ldpc_code *code, size_t *distance, int *found)
-{
+try {
     if (!code || !distance || !found) return fail(LDPC_ERR_BAD_ARG, "null argument");
     uint32_t w = 0;
     if (!minimal_row_span_weight(nullspace(code->host.h), w))
@@ -748,14 +770,16 @@ int ldpc_code_minimal_distance(const ldpc_code *code, size_t *distance, int *fou
     *distance = w;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_has_same_codespace(const ldpc_code *code, const ldpc_code *other, int *out)
-{
+try {
     if (!code || !other || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     // mod.rs:272-275: same length and H * G_other^T == 0
     *out = code->host.len() == other->host.len() && code->host.h.product_is_zero(nullspace(other->host.h));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 static int give_text(const std::string &s, char *buf, size_t capacity, size_t *needed)
 {
@@ -767,13 +791,14 @@ static int give_text(const std::string &s, char *buf, size_t capacity, size_t *n
 }
 
 int ldpc_code_as_json(const ldpc_code *code, char *buf, size_t capacity, size_t *needed)
-{
+try {
     if (!code || !needed) return fail(LDPC_ERR_BAD_ARG, "null argument");
     return give_text(linear_code_to_json(code->host), buf, capacity, needed);
 }
+LDPC_CATCH
 
 int ldpc_code_from_json(const char *text, size_t len, ldpc_code **out)
-{
+try {
     if (!text || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     LinearCode c;
     std::string err;
@@ -781,9 +806,10 @@ int ldpc_code_from_json(const char *text, size_t len, ldpc_code **out)
     *out = new_code(std::move(c));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_edges(const ldpc_code *code, size_t *bits, size_t *checks)
-{
+try {
     if (!code || ((!bits || !checks) && code->host.h.nnz())) return fail(LDPC_ERR_BAD_ARG, "null argument");
     const SparseBinMat &h = code->host.h;
     for (uint32_t r = 0; r < h.nrows(); r++)
@@ -793,9 +819,10 @@ int ldpc_code_edges(const ldpc_code *code, size_t *bits, size_t *checks)
         }
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_syndrome_batch(const ldpc_code *code, size_t n_shots, const uint64_t *d_words, uint64_t *d_syndromes)
-{
+try {
     if (!code || (n_shots && (!d_words || !d_syndromes))) return fail(LDPC_ERR_BAD_ARG, "null argument");
     int st = code->ensure_device();
     if (st) return st;
@@ -804,10 +831,11 @@ int ldpc_code_syndrome_batch(const ldpc_code *code, size_t n_shots, const uint64
     timer.stop_and_store();
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_syndrome_of(const ldpc_code *code, size_t len, const size_t *positions, size_t n_positions,
                           size_t *out_positions, size_t *out_n)
-{
+try {
     if (!code || !out_n || (n_positions && !positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (len != code->host.len())
         return fail(LDPC_ERR_LENGTH_MISMATCH, "message of length " + std::to_string(len) +
@@ -835,9 +863,10 @@ int ldpc_code_syndrome_of(const ldpc_code *code, size_t len, const size_t *posit
     *out_n = k;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_code_has_codeword(const ldpc_code *code, size_t len, const size_t *positions, size_t n_positions, int *out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     size_t k = 0;
     int st = ldpc_code_syndrome_of(code, len, positions, n_positions, nullptr, &k);
@@ -845,13 +874,14 @@ int ldpc_code_has_codeword(const ldpc_code *code, size_t len, const size_t *posi
     *out = k == 0;   // mod.rs:435
     return LDPC_OK;
 }
+LDPC_CATCH
 
 void ldpc_code_destroy(ldpc_code *code) { delete code; }
 
 // ---- noise ----------------------------------------------------------------
 int ldpc_bsc_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot, size_t n_shots,
                           uint64_t *d_words)
-{
+try {
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
     if (n_shots && len && !d_words) return fail(LDPC_ERR_BAD_ARG, "null argument");
@@ -860,10 +890,11 @@ int ldpc_bsc_sample_batch(double probability, size_t len, uint64_t seed, uint64_
     timer.stop_and_store();
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_depolarizing_sample_batch(double probability, size_t len, uint64_t seed, uint64_t first_shot, size_t n_shots,
                                    uint64_t *d_x_words, uint64_t *d_z_words)
-{
+try {
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
     if (n_shots && len && (!d_x_words || !d_z_words)) return fail(LDPC_ERR_BAD_ARG, "null argument");
@@ -873,10 +904,11 @@ int ldpc_depolarizing_sample_batch(double probability, size_t len, uint64_t seed
     timer.stop_and_store();
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_bsc_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot, size_t *out_positions,
                                     size_t *out_n)
-{
+try {
     if (!out_n || (len && !out_positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     std::vector<uint64_t> w(std::max<size_t>(words_for(len), 1), 0);
     DeviceBuffer d;
@@ -888,17 +920,19 @@ int ldpc_bsc_sample_error_of_length(double probability, size_t len, uint64_t see
     unpack(w, len, out_positions, out_n);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_erasure_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
                                         size_t *out_positions, size_t *out_n)
-{
+try {
     // noise/erasure.rs:33-42 draws the same n i.i.d. Bernoulli(p) bits as the binary symmetric channel
     return ldpc_bsc_sample_error_of_length(probability, len, seed, shot, out_positions, out_n);
 }
+LDPC_CATCH
 
 int ldpc_depolarizing_sample_error_of_length(double probability, size_t len, uint64_t seed, uint64_t shot,
                                              size_t *out_positions, uint8_t *out_paulis, size_t *out_n)
-{
+try {
     if (!out_n || (len && (!out_positions || !out_paulis))) return fail(LDPC_ERR_BAD_ARG, "null argument");
     size_t W = std::max<size_t>(words_for(len), 1);
     std::vector<uint64_t> x(W, 0), z(W, 0);
@@ -924,20 +958,22 @@ int ldpc_depolarizing_sample_error_of_length(double probability, size_t len, uin
     *out_n = k;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 // ---- FlipDecoder ----------------------------------------------------------
 int ldpc_flip_create(const ldpc_code *code, ldpc_flip_decoder **out)
-{
+try {
     if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     ldpc_flip_decoder *d = new ldpc_flip_decoder();
     copy_code(d->code, code->host);
     *out = d;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_flip_decode_batch(ldpc_flip_decoder *dec, size_t n_shots, const uint64_t *d_words_in, uint64_t *d_words_out,
                            uint64_t *d_syndromes_out, uint32_t *d_flips_out)
-{
+try {
     if (!dec || (n_shots && !d_words_in)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     FlipArgs a{};
     a.source = SRC_WORDS;
@@ -949,10 +985,11 @@ int ldpc_flip_decode_batch(ldpc_flip_decoder *dec, size_t n_shots, const uint64_
     a.gap = make_gap_table(0.0);
     return run_flip(dec, a, nullptr);
 }
+LDPC_CATCH
 
 int ldpc_flip_decode(ldpc_flip_decoder *dec, size_t len, const size_t *positions, size_t n_positions,
                      size_t *out_positions, size_t *out_n)
-{
+try {
     if (!dec || !out_n || (n_positions && !positions) || (len && !out_positions)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (len != dec->code.host.len())
         return fail(LDPC_ERR_LENGTH_MISMATCH, "message of length " + std::to_string(len) +
@@ -975,11 +1012,12 @@ int ldpc_flip_decode(ldpc_flip_decoder *dec, size_t len, const size_t *positions
     unpack(out, len, out_positions, out_n);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, uint64_t first_shot, size_t n_shots,
                      uint64_t counters[LDPC_COUNTERS], uint64_t *d_errors_out, uint64_t *d_syndromes_out,
                      uint64_t *d_words_out)
-{
+try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     FlipArgs a{};
@@ -994,12 +1032,13 @@ int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, 
     a.list_cap = flip2_list_cap((double)dec->code.host.len() * probability);   // error list sized for the channel
     return run_flip(dec, a, counters);
 }
+LDPC_CATCH
 
 void ldpc_flip_destroy(ldpc_flip_decoder *dec) { delete dec; }
 
 // ---- BpDecoder ------------------------------------------------------------
 int ldpc_bp_create(const ldpc_code *code, double probability, size_t max_iterations, ldpc_bp_decoder **out)
-{
+try {
     if (!code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     std::unique_ptr<ldpc_bp_decoder> d(new ldpc_bp_decoder());
     int st = init_bp(d.get(), code->host, probability, max_iterations);
@@ -1007,10 +1046,11 @@ int ldpc_bp_create(const ldpc_code *code, double probability, size_t max_iterati
     *out = d.release();
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_bp_correction_for_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_syndromes,
                                  uint64_t *d_corrections_out, uint32_t *d_iterations_out, double *d_posteriors_out)
-{
+try {
     if (!dec || (n_shots && !d_syndromes)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     BpRun r;
     r.source = SRC_SYNDROMES;
@@ -1023,10 +1063,11 @@ int ldpc_bp_correction_for_batch(ldpc_bp_decoder *dec, size_t n_shots, const uin
     r.gap = make_gap_table(0.0);
     return run_bp(dec, r, nullptr);
 }
+LDPC_CATCH
 
 int ldpc_bp_decode_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_words_in, uint64_t *d_words_out,
                          uint32_t *d_iterations_out)
-{
+try {
     if (!dec || (n_shots && !d_words_in)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     BpRun r;
     r.source = SRC_WORDS;
@@ -1039,6 +1080,7 @@ int ldpc_bp_decode_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d
     r.gap = make_gap_table(0.0);
     return run_bp(dec, r, nullptr);
 }
+LDPC_CATCH
 
 static int bp_single(ldpc_bp_decoder *dec, bool is_syndrome, size_t len, const size_t *positions, size_t n_positions,
                      size_t *out_positions, size_t *out_n)
@@ -1073,19 +1115,21 @@ static int bp_single(ldpc_bp_decoder *dec, bool is_syndrome, size_t len, const s
 
 int ldpc_bp_correction_for(ldpc_bp_decoder *dec, size_t syndrome_len, const size_t *syndrome_positions,
                            size_t n_positions, size_t *out_positions, size_t *out_n)
-{
+try {
     return bp_single(dec, true, syndrome_len, syndrome_positions, n_positions, out_positions, out_n);
 }
+LDPC_CATCH
 
 int ldpc_bp_decode(ldpc_bp_decoder *dec, size_t len, const size_t *positions, size_t n_positions, size_t *out_positions,
                    size_t *out_n)
-{
+try {
     return bp_single(dec, false, len, positions, n_positions, out_positions, out_n);
 }
+LDPC_CATCH
 
 int ldpc_bp_mc_run(ldpc_bp_decoder *dec, double noise_probability, uint64_t seed, uint64_t first_shot, size_t n_shots,
                    uint64_t counters[LDPC_COUNTERS], uint8_t *d_failed_out)
-{
+try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     BpRun r;
@@ -1100,6 +1144,7 @@ int ldpc_bp_mc_run(ldpc_bp_decoder *dec, double noise_probability, uint64_t seed
     if (d_failed_out && n_shots) HIP_TRY(hipMemsetAsync(d_failed_out, 0, n_shots, g_stream));
     return run_bp(dec, r, counters);
 }
+LDPC_CATCH
 
 void ldpc_bp_destroy(ldpc_bp_decoder *dec) { delete dec; }
 
@@ -1115,7 +1160,7 @@ static ldpc_css_code *new_css(const CssCode &c)
 }
 
 int ldpc_css_create(const ldpc_code *x_code, const ldpc_code *z_code, ldpc_css_code **out)
-{
+try {
     if (!x_code || !z_code || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     CssCode c;
     int e = css_try_new(x_code->host, z_code->host, c);
@@ -1126,10 +1171,11 @@ int ldpc_css_create(const ldpc_code *x_code, const ldpc_code *z_code, ldpc_css_c
     *out = new_css(c);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_create_with_logicals(const ldpc_code *x_stabs, const ldpc_code *z_stabs, const ldpc_code *x_logicals,
                                   const ldpc_code *z_logicals, ldpc_css_code **out)
-{
+try {
     if (!x_stabs || !z_stabs || !x_logicals || !z_logicals || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     size_t n = x_stabs->host.len();
     if (z_stabs->host.len() != n || x_logicals->host.len() != n || z_logicals->host.len() != n)
@@ -1142,9 +1188,10 @@ int ldpc_css_create_with_logicals(const ldpc_code *x_stabs, const ldpc_code *z_s
     *out = new_css(c);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_shor(ldpc_css_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     std::string err;
     SparseBinMat hx, hz, lx, lz;
@@ -1160,9 +1207,10 @@ int ldpc_css_shor(ldpc_css_code **out)
     *out = new_css(c);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_steane(ldpc_css_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     CssCode c;
     LinearCode h = hamming_code();
@@ -1170,6 +1218,7 @@ int ldpc_css_steane(ldpc_css_code **out)
     *out = new_css(c);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 static int hgp(const LinearCode &a, const LinearCode &b, ldpc_css_code **out)
 {
@@ -1186,13 +1235,14 @@ static int hgp(const LinearCode &a, const LinearCode &b, ldpc_css_code **out)
 }
 
 int ldpc_css_hypergraph_product(const ldpc_code *first, const ldpc_code *second, ldpc_css_code **out)
-{
+try {
     if (!first || !second || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     return hgp(first->host, second->host, out);
 }
+LDPC_CATCH
 
 int ldpc_css_toric(size_t distance, ldpc_css_code **out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (distance < 2 || distance > 400) return fail(LDPC_ERR_BAD_ARG, "invalid toric code distance");
     std::vector<std::vector<uint32_t>> rows;                      // css/mod.rs:85-88
@@ -1204,6 +1254,7 @@ int ldpc_css_toric(size_t distance, ldpc_css_code **out)
     LinearCode code = make_code(h);
     return hgp(code, code, out);
 }
+LDPC_CATCH
 
 size_t ldpc_css_len(const ldpc_css_code *css) { return css ? css->m[0].host.len() : 0; }
 
@@ -1215,17 +1266,18 @@ const ldpc_code *ldpc_css_matrix(const ldpc_css_code *css, int which)
 
 int ldpc_css_syndrome_of(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x, const size_t *z_part,
                          size_t n_z, size_t *out_sx, size_t *out_n_sx, size_t *out_sz, size_t *out_n_sz)
-{
+try {
     if (!css || !out_n_sx || !out_n_sz) return fail(LDPC_ERR_BAD_ARG, "null argument");
     // css/mod.rs:200-205: stabilizers.pair(operator.swap_xz()): Hx * z_part, Hz * x_part
     int st = ldpc_code_syndrome_of(&css->m[0], len, z_part, n_z, out_sx, out_n_sx);
     if (st) return st;
     return ldpc_code_syndrome_of(&css->m[1], len, x_part, n_x, out_sz, out_n_sz);
 }
+LDPC_CATCH
 
 int ldpc_css_has_logical(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x, const size_t *z_part,
                          size_t n_z, int *out)
-{
+try {
     if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     size_t a = 0, b = 0;
     int st = ldpc_css_syndrome_of(css, len, x_part, n_x, z_part, n_z, nullptr, &a, nullptr, &b);
@@ -1233,10 +1285,11 @@ int ldpc_css_has_logical(const ldpc_css_code *css, size_t len, const size_t *x_p
     *out = (a == 0 && b == 0);   // css.rs:137-139 is_trivial
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_has_stabilizer(const ldpc_css_code *css, size_t len, const size_t *x_part, size_t n_x,
                             const size_t *z_part, size_t n_z, int *out)
-{
+try {
     if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     int logical = 0;
     int st = ldpc_css_has_logical(css, len, x_part, n_x, z_part, n_z, &logical);
@@ -1251,10 +1304,11 @@ int ldpc_css_has_stabilizer(const ldpc_css_code *css, size_t len, const size_t *
     *out = logical && a == 0 && b == 0;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_erasure_num_bad_errors(const ldpc_css_code *css, size_t len, const size_t *erasure, size_t n_erased,
                                     size_t *bad_x, size_t *bad_z)
-{
+try {
     if (!css || !bad_x || !bad_z || (n_erased && !erasure)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (len != css->m[0].host.len())
         return fail(LDPC_ERR_LENGTH_MISMATCH, "erasure of length " + std::to_string(len) + " is invalid for code with length " +
@@ -1266,10 +1320,11 @@ int ldpc_css_erasure_num_bad_errors(const ldpc_css_code *css, size_t len, const 
     *bad_z = erasure_num_bad_errors(css->m[0].host.h, css->m[2].host.h, e);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, const size_t *erasure, size_t n_erased,
                                           double *out)
-{
+try {
     if (!out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     size_t bx = 0, bz = 0;
     int st = ldpc_css_erasure_num_bad_errors(css, len, erasure, n_erased, &bx, &bz);
@@ -1277,9 +1332,10 @@ int ldpc_css_erasure_recovery_probability(const ldpc_css_code *css, size_t len, 
     *out = std::ldexp(1.0, -(int)(bx + bz));   // css_erasure.rs:60-64
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_as_json(const ldpc_css_code *css, char *buf, size_t capacity, size_t *needed)
-{
+try {
     if (!css || !needed) return fail(LDPC_ERR_BAD_ARG, "null argument");
     CssCode c;
     c.hx = css->m[0].host;
@@ -1288,9 +1344,10 @@ int ldpc_css_as_json(const ldpc_css_code *css, char *buf, size_t capacity, size_
     c.lz = css->m[3].host;
     return give_text(css_code_to_json(c), buf, capacity, needed);
 }
+LDPC_CATCH
 
 int ldpc_css_from_json(const char *text, size_t len, ldpc_css_code **out)
-{
+try {
     if (!text || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     CssCode c;
     std::string err;
@@ -1301,12 +1358,13 @@ int ldpc_css_from_json(const char *text, size_t len, ldpc_css_code **out)
     *out = new_css(c);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 void ldpc_css_destroy(ldpc_css_code *css) { delete css; }
 
 // ---- CssDecoder<BpDecoder> -------------------------------------------------
 int ldpc_css_bp_create(const ldpc_css_code *css, double probability, size_t max_iterations, ldpc_css_bp_decoder **out)
-{
+try {
     if (!css || !out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     std::unique_ptr<ldpc_css_bp_decoder> d(new ldpc_css_bp_decoder());
     int st = init_bp(&d->x, css->m[0].host, probability, max_iterations);   // css_decoding.rs:42
@@ -1318,10 +1376,11 @@ int ldpc_css_bp_create(const ldpc_css_code *css, double probability, size_t max_
     *out = d.release();
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_bp_correction_for(ldpc_css_bp_decoder *dec, const size_t *sx, size_t n_sx, const size_t *sz, size_t n_sz,
                                size_t *out_cx, size_t *out_n_cx, size_t *out_cz, size_t *out_n_cz)
-{
+try {
     if (!dec) return fail(LDPC_ERR_BAD_ARG, "null argument");
     // decoders/css.rs:10-15: pair(x decoder, syndrome.x), pair(z decoder, syndrome.z), then swap_xz.  The two
     // decodes are independent and each is a handful of launch-bound rounds: the second runs from a host thread of
@@ -1332,7 +1391,7 @@ int ldpc_css_bp_correction_for(ldpc_css_bp_decoder *dec, const size_t *sx, size_
     if (!dec->side_stream) HIP_TRY(hipStreamCreateWithFlags(&dec->side_stream, hipStreamNonBlocking));
     int st_z = LDPC_OK;
     std::string err_z;
-    std::thread other([&]() {
+    auto z_half = [&]() {
         if (hipSetDevice(dev) != hipSuccess) {
             st_z = LDPC_ERR_HIP;
             err_z = "hipSetDevice failed";
@@ -1341,17 +1400,26 @@ int ldpc_css_bp_correction_for(ldpc_css_bp_decoder *dec, const size_t *sx, size_
         g_stream = dec->side_stream;
         st_z = ldpc_bp_correction_for(&dec->z, dec->z.code.host.num_checks(), sz, n_sz, out_cx, out_n_cx);
         if (st_z) err_z = g_error;
-    });
+    };
+    std::thread other;
+    bool beside = true;
+    try {
+        other = std::thread(z_half);
+    } catch (...) {   // no thread to be had: one after the other (nothing may unwind across the C ABI)
+        beside = false;
+    }
     const int st = ldpc_bp_correction_for(&dec->x, dec->x.code.host.num_checks(), sx, n_sx, out_cz, out_n_cz);
-    other.join();
+    if (beside) other.join();
+    else return st ? st : ldpc_bp_correction_for(&dec->z, dec->z.code.host.num_checks(), sz, n_sz, out_cx, out_n_cx);
     if (st) return st;
     if (st_z) return fail(st_z, err_z);
     return LDPC_OK;
 }
+LDPC_CATCH
 
 int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint64_t seed, uint64_t first_shot,
                        size_t n_shots, uint64_t counters[LDPC_COUNTERS])
-{
+try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
     std::lock_guard<std::mutex> lock(dec->mu);
@@ -1404,7 +1472,7 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
             int st_x = LDPC_OK;
             std::string err_x;
             double ms_x = 0.0;
-            std::thread other([&]() {
+            auto x_half = [&]() {
                 hipStream_t sx = nullptr;
                 if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&sx, hipStreamNonBlocking) != hipSuccess) {
                     st_x = LDPC_ERR_HIP;
@@ -1417,7 +1485,14 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
                 ms_x = g_last_ms;
                 (void)hipStreamSynchronize(sx);
                 (void)hipStreamDestroy(sx);
-            });
+            };
+            std::thread other;
+            bool beside = true;
+            try {
+                other = std::thread(x_half);
+            } catch (...) {   // no thread to be had: this thread runs the half itself, below
+                beside = false;
+            }
             // (this half too runs on a stream of its own: the null stream would order itself against the other)
             hipStream_t caller = g_stream, sz = nullptr;
             int st = LDPC_OK;
@@ -1432,7 +1507,13 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
                 g_stream = caller;
             }
             const double ms_z = g_last_ms;
-            other.join();
+            if (beside) other.join();
+            else if (!st) {
+                hipStream_t caller2 = g_stream;
+                x_half();            // sets g_stream to its own stream
+                g_stream = caller2;
+                ms_x += ms_z;        // in turn: the times add
+            }
             if (st) return st;
             if (st_x) return fail(st_x, err_x);
             ms_total += std::max(ms_z, ms_x);
@@ -1461,6 +1542,7 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
     g_last_ms = ms_total;
     return LDPC_OK;
 }
+LDPC_CATCH
 
 void ldpc_css_bp_destroy(ldpc_css_bp_decoder *dec) { delete dec; }
 
@@ -1477,8 +1559,7 @@ int run_multi(int n_devices, const int *devices, uint64_t first_shot, size_t n_s
     std::vector<int> status((size_t)n_devices, LDPC_OK);
     std::vector<std::string> message((size_t)n_devices);
     std::vector<std::thread> threads;
-    for (int k = 0; k < n_devices; k++)
-        threads.emplace_back([&, k]() {
+    auto shard_k = [&](int k) {
             part[(size_t)k].fill(0);
             const size_t lo = (size_t)((unsigned __int128)n_shots * (unsigned)k / (unsigned)n_devices),
                          hi = (size_t)((unsigned __int128)n_shots * (unsigned)(k + 1) / (unsigned)n_devices);
@@ -1486,8 +1567,17 @@ int run_multi(int n_devices, const int *devices, uint64_t first_shot, size_t n_s
             if (!st) st = shard(first_shot + lo, hi - lo, part[(size_t)k].data());
             status[(size_t)k] = st;
             if (st) message[(size_t)k] = ldpc_last_error();
-        });
+    };
+    bool spawned = true;
+    for (int k = 0; k < n_devices && spawned; k++) {
+        try {
+            threads.emplace_back(shard_k, k);
+        } catch (...) {   // nothing may unwind across the C ABI
+            spawned = false;
+        }
+    }
     for (auto &t : threads) t.join();
+    if (!spawned) return fail(LDPC_ERR_HIP, "could not start a host thread per device");
     for (int i = 0; i < LDPC_COUNTERS; i++) counters[i] = 0;
     for (int k = 0; k < n_devices; k++) {
         if (status[(size_t)k]) return fail(status[(size_t)k], "device shard " + std::to_string(k) + ": " + message[(size_t)k]);
@@ -1500,7 +1590,7 @@ int run_multi(int n_devices, const int *devices, uint64_t first_shot, size_t n_s
 
 int ldpc_flip_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability, uint64_t seed,
                            uint64_t first_shot, size_t n_shots, uint64_t counters[LDPC_COUNTERS])
-{
+try {
     if (!code) return fail(LDPC_ERR_BAD_ARG, "null argument");
     return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
         ldpc_flip_decoder *dec = nullptr;
@@ -1510,11 +1600,12 @@ int ldpc_flip_mc_run_multi(const ldpc_code *code, int n_devices, const int *devi
         return st;
     });
 }
+LDPC_CATCH
 
 int ldpc_bp_mc_run_multi(const ldpc_code *code, int n_devices, const int *devices, double probability,
                          size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
                          uint64_t counters[LDPC_COUNTERS])
-{
+try {
     if (!code) return fail(LDPC_ERR_BAD_ARG, "null argument");
     return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
         ldpc_bp_decoder *dec = nullptr;
@@ -1524,11 +1615,12 @@ int ldpc_bp_mc_run_multi(const ldpc_code *code, int n_devices, const int *device
         return st;
     });
 }
+LDPC_CATCH
 
 int ldpc_css_bp_mc_run_multi(const ldpc_css_code *css, int n_devices, const int *devices, double probability,
                              size_t max_iterations, uint64_t seed, uint64_t first_shot, size_t n_shots,
                              uint64_t counters[LDPC_COUNTERS])
-{
+try {
     if (!css) return fail(LDPC_ERR_BAD_ARG, "null argument");
     return run_multi(n_devices, devices, first_shot, n_shots, counters, [&](uint64_t first, size_t count, uint64_t *c) {
         ldpc_css_bp_decoder *dec = nullptr;
@@ -1538,15 +1630,17 @@ int ldpc_css_bp_mc_run_multi(const ldpc_css_code *css, int n_devices, const int 
         return st;
     });
 }
+LDPC_CATCH
 
 // Not part of the drop-in ABI (absent from include/ldpc_hip.h): lets the tests measure the
 // accuracy of the BP kernel's tanh(x/2) / log1p routines (csrc/bp_math.hpp) on device arrays.
 int ldpc_internal_bp_math(int kind, size_t n, const double *d_in, double *d_out)
-{
+try {
     if (n && (!d_in || !d_out)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     HIP_TRY(launch_bp_math_probe(kind, n, d_in, d_out, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return LDPC_OK;
 }
+LDPC_CATCH
 
 }  // extern "C"
