@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--shots-per-step", type=int, default=1 << 20, help="shots per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bp", action="store_true", help="skip the secondary BP measurement")
+    ap.add_argument("--decoder", choices=("flip", "bp"), default="flip",
+                    help="flip (default): the headline line.  bp: the same contract with the f64 BP decoder as the step "
+                         "(Monte-Carlo mode, counters only), e.g. for its scaling over N GPUs")
     args = ap.parse_args()
 
     import torch
@@ -154,12 +157,20 @@ def main():
     B = args.shots_per_step
     wn, wm = ldpc_amd.nwords(N_BITS), ldpc_amd.nwords(N_CHECKS)
     bytes_per_shot = 2 * wn * 8 + wm * 8
-    d_err = torch.empty((B, wn), dtype=torch.int64, device="cuda")
-    d_syn = torch.empty((B, wm), dtype=torch.int64, device="cuda")
-    d_out = torch.empty((B, wn), dtype=torch.int64, device="cuda")
+    use_bp = args.decoder == "bp"
+    if not use_bp:
+        d_err = torch.empty((B, wn), dtype=torch.int64, device="cuda")
+        d_syn = torch.empty((B, wm), dtype=torch.int64, device="cuda")
+        d_out = torch.empty((B, wn), dtype=torch.int64, device="cuda")
+
+    if use_bp:
+        from ldpc_amd import BpDecoder
+        bp_dec = BpDecoder(code, P, 100)
 
     def step(s):
         first = (s * world + rank) * B        # global shot index: disjoint across ranks and steps
+        if use_bp:
+            return bp_dec.mc_run(P, NOISE_SEED, first, B)
         return dec.mc_run(P, NOISE_SEED, first, B, d_err, d_syn, d_out)
 
     def barrier():
@@ -216,12 +227,31 @@ def main():
             },
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
         }
-        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not use_bp:   # reported at N = 1 only
             cb, _ = cpu_baseline(code)
             line["cpu_baseline"] = cb
-        if not args.no_bp and world == 1:
+        if not args.no_bp and world == 1 and not use_bp:
             line["bp"] = bp_line(code)
             line["bp_c5"] = bp_c5_line()
+        if use_bp:
+            # BP step: algorithmic bytes = 32 E per shot-iteration, iterations from the all-reduced counter
+            alg = float(counters[ldpc_amd.CNT_WORK]) / world / args.steps * 32 * code.num_edges()
+            line["dtype"] = "f64"
+            line["config"]["workload"] = ("configs[1] with the BP decoder: random (3,6)-regular LDPC n=10000 m=5000 (code_seed=1), "
+                                          "BSC p=0.02, Philox noise_seed=2024, BpDecoder f64 max 100 iterations, fused "
+                                          "sample+syndrome+decode+failure test, counters only")
+            line["roofline"] = {"bound": "hbm", "achieved": alg / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "kernel": "bp_kernel<6,3>", "kernel_ms": avg_kernel_s * 1e3,
+                                "algorithmic_bytes_per_shot_iteration": 32 * code.num_edges()}
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_bp_pmc.json")) as f:
+                    line["roofline"]["traffic"] = json.load(f)["traffic_over_algorithmic"] * alg
+            except Exception:
+                pass
+            line.pop("cpu_baseline", None)
+            line.pop("bp", None)
+            line.pop("bp_c5", None)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
