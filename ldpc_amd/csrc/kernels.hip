@@ -693,7 +693,9 @@ constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // next to the other waves of the SIMD, few enough to stay inside 128 registers.
 template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
 {
-    constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : 3;
+    // (measured: degree 6 in two batches of 3 -- one batch of 6 is no faster, 2 + 2 + 2 is 1 % slower; degree 7 as
+    // 4 + 3 -- 6 % faster on the CSS example than 3 + 3 + 1, 2 % faster than one batch of 7)
+    constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : DC == 7 ? 4 : 3;
     double prod = 1.0;
 #pragma unroll
     for (int j = 0; j < DC; j++) prod *= t[j];
