@@ -227,7 +227,7 @@ struct ldpc_bp_decoder {
     DeviceBuffer counters, workspace, stream_state;
     std::mutex io_mu;               // single-vector staging, as in ldpc_code
     DeviceBuffer io_in, io_out;
-    int reg_dc = 0, reg_dv = 0;   // common check / bit degree when the code is regular, else 0
+    int reg_dc = 0, reg_dv = 0;   // common check / bit degree when the code is regular, else 0 (reg_dv = -4: mixed, none above 4)
 };
 
 struct ldpc_css_bp_decoder {
@@ -557,6 +557,9 @@ int init_bp(ldpc_bp_decoder *d, const LinearCode &code, double p, size_t max_ite
             if ((int)h.row_len(r) != dc) dc = 0;
         for (uint32_t r = 0; r < t.nrows(); r++)
             if ((int)t.row_len(r) != dv) dv = 0;
+        // (bits of mixed degree, none above 4 -- the hypergraph-product codes: the any-degree bit update with row
+        // registers for four checks instead of eight)
+        if (dv == 0 && t.nrows() && t.max_row_len() <= 4) dv = -4;
         d->reg_dc = dc;
         d->reg_dv = dv;
     }

@@ -818,10 +818,12 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32
                 }
         }
     } else {
-        // any degrees.  The chunk's edge-list bounds (lane i = bit b0 + i) and, when they fit four registers
+        // any degrees (DV = 0), or any degrees up to -DV (DV < 0: the row registers are sized for that, half of the
+        // general eight when the code has no bit of degree above 4).  The chunk's edge-list bounds (lane i = bit b0 + i) and, when they fit four registers
         // (<= 256 edges in the chunk), the edge list itself are fetched once and read back as scalars, so row
         // addresses are scalar and no row load waits on an index load; the rows of the next bit are in flight
         // while the current bit is worked.
+        constexpr uint32_t RD = DV < 0 ? (uint32_t)(-DV) : REG_DEG;
         const uint32_t nbits = b1 - b0;
         const uint32_t myk0 = b0 + lane < b1 ? g.t_ptr[b0 + lane] : 0u, myk1 = b0 + lane < b1 ? g.t_ptr[b0 + lane + 1] : 0u;
         const uint32_t kstart = __builtin_amdgcn_readlane(myk0, 0), cnt = __builtin_amdgcn_readlane(myk1, nbits - 1) - kstart;
@@ -839,17 +841,17 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32
                            a2 = __builtin_amdgcn_readlane(me[2], l), a3 = __builtin_amdgcn_readlane(me[3], l);
             return qd == 0 ? a0 : qd == 1 ? a1 : qd == 2 ? a2 : a3;
         };
-        double vn[REG_DEG];
-        uint32_t edn[REG_DEG];
+        double vn[RD];
+        uint32_t edn[RD];
 #pragma unroll
-        for (uint32_t k = 0; k < REG_DEG; k++) {
+        for (uint32_t k = 0; k < RD; k++) {
             vn[k] = 0.0;
             edn[k] = 0;
         }
         uint32_t k0n = kstart, dvn = nbits ? __builtin_amdgcn_readlane(myk1, 0) - kstart : 0u;
-        if (dvn <= REG_DEG) {
+        if (dvn <= RD) {
 #pragma unroll
-            for (uint32_t k = 0; k < REG_DEG; k++)
+            for (uint32_t k = 0; k < RD; k++)
                 if (k < dvn) {
                     edn[k] = edge(k0n + k);
                     vn[k] = chkm[(size_t)edn[k] * 64 + lane];
@@ -858,38 +860,38 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32
         for (uint32_t i = 0; i < nbits; i++) {
             const uint32_t k0 = k0n, dv = dvn;
             double sum = 0.0, post = prior;
-            double v[REG_DEG];
-            uint32_t ed[REG_DEG];
+            double v[RD];
+            uint32_t ed[RD];
 #pragma unroll
-            for (uint32_t k = 0; k < REG_DEG; k++) {
+            for (uint32_t k = 0; k < RD; k++) {
                 v[k] = vn[k];
                 ed[k] = edn[k];
             }
             if (i + 1 < nbits) {
                 k0n = __builtin_amdgcn_readlane(myk0, i + 1);
                 dvn = __builtin_amdgcn_readlane(myk1, i + 1) - k0n;
-                if (dvn <= REG_DEG) {
+                if (dvn <= RD) {
 #pragma unroll
-                    for (uint32_t k = 0; k < REG_DEG; k++)
+                    for (uint32_t k = 0; k < RD; k++)
                         if (k < dvn) {
                             edn[k] = edge(k0n + k);
                             vn[k] = chkm[(size_t)edn[k] * 64 + lane];
                         }
                 }
             }
-            if (dv <= REG_DEG) {
+            if (dv <= RD) {
 #pragma unroll
-                for (uint32_t k = 0; k < REG_DEG; k++)
+                for (uint32_t k = 0; k < RD; k++)
                     if (k < dv) {
                         sum += v[k];
                         post += v[k];
                     }
-                double tm[REG_DEG];
+                double tm[RD];
 #pragma unroll
-                for (uint32_t k = 0; k < REG_DEG; k++)
+                for (uint32_t k = 0; k < RD; k++)
                     if (k < dv) tm[k] = bp_tanh_half(sum - v[k] + prior);
 #pragma unroll
-                for (uint32_t k = 0; k < REG_DEG; k++)
+                for (uint32_t k = 0; k < RD; k++)
                     if (k < dv && active) bitsm[(size_t)ed[k] * 64 + lane] = tm[k];
             } else {
                 for (uint32_t k = 0; k < dv; k++) {
@@ -1810,7 +1812,9 @@ static bp_kernel_fn bp_kernel_for(int dc, int dv)
 {
     if (dc == 6 && dv == 3) return bp_kernel<6, 3>;
     if (dc == 4 && dv == 3) return bp_kernel<4, 3>;
+    if (dc == 7 && dv == -4) return bp_kernel<7, -4>;
     if (dc == 7) return bp_kernel<7, 0>;
+    if (dv == -4) return bp_kernel<0, -4>;
     return bp_kernel<0, 0>;
 }
 
@@ -1922,7 +1926,9 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         const dim3 grid((gcn + gbn) * parts);
         if (dc == 6 && dv == 3) hipLaunchKernelGGL((bps_iterate<6, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bps_iterate<4, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (dc == 7 && dv == -4) hipLaunchKernelGGL((bps_iterate<7, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (dv == -4) hipLaunchKernelGGL((bps_iterate<0, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
     };
     // Tail compaction (bps_compact): when the shots left fill at most 3/4 of the slots of the groups in play, move
