@@ -1812,9 +1812,12 @@ static bp_kernel_fn bp_kernel_for(int dc, int dv)
 {
     if (dc == 6 && dv == 3) return bp_kernel<6, 3>;
     if (dc == 4 && dv == 3) return bp_kernel<4, 3>;
-    if (dc == 7 && dv == -4) return bp_kernel<7, -4>;
+    // dv = -4: bits of mixed degree, none above 4; a regular bit degree up to 4 without a kernel of its own is served
+    // by the same instantiation
+    const bool small_dv = dv == -4 || (dv >= 1 && dv <= 4);
+    if (dc == 7 && small_dv) return bp_kernel<7, -4>;
     if (dc == 7) return bp_kernel<7, 0>;
-    if (dv == -4) return bp_kernel<0, -4>;
+    if (small_dv) return bp_kernel<0, -4>;
     return bp_kernel<0, 0>;
 }
 
@@ -1924,11 +1927,12 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     auto iterate = [&](int c, int b) {
         const uint32_t gc0 = c >= 0 ? set0[c] : 0, gcn = c >= 0 ? setn[c] : 0, gb0 = b >= 0 ? set0[b] : 0, gbn = b >= 0 ? setn[b] : 0;
         const dim3 grid((gcn + gbn) * parts);
+        const bool small_dv = dv == -4 || (dv >= 1 && dv <= 4);   // as in bp_kernel_for
         if (dc == 6 && dv == 3) hipLaunchKernelGGL((bps_iterate<6, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else if (dc == 4 && dv == 3) hipLaunchKernelGGL((bps_iterate<4, 3>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
-        else if (dc == 7 && dv == -4) hipLaunchKernelGGL((bps_iterate<7, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (dc == 7 && small_dv) hipLaunchKernelGGL((bps_iterate<7, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else if (dc == 7) hipLaunchKernelGGL((bps_iterate<7, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
-        else if (dv == -4) hipLaunchKernelGGL((bps_iterate<0, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
+        else if (small_dv) hipLaunchKernelGGL((bps_iterate<0, -4>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
         else hipLaunchKernelGGL((bps_iterate<0, 0>), grid, blk, 0, st, g, a, s, parts, gc0, gcn, gb0, gbn, bsplit);
     };
     // Tail compaction (bps_compact): when the shots left fill at most 3/4 of the slots of the groups in play, move
