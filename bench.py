@@ -98,6 +98,29 @@ def bp_line(code, shots=1 << 23):
                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}}
 
 
+def css_line(shots=1 << 23):
+    """Secondary measurement: configs[2], the CSS code of examples/css_decoding.rs (hypergraph product of a
+    (3,4)-regular n = 20 code with itself: 625 qubits), depolarizing p = 0.01, CssDecoder<BpDecoder> max 100
+    iterations, X and Z halves decoded independently.  Algorithmic bytes = 32 * 2100 per shot-iteration of a half."""
+    import ldpc_amd
+    from ldpc_amd import CssCode, CssDecoder, LinearCode
+    base = LinearCode.random_regular_code(20, 15, 3, 4, seed=CODE_SEED)
+    css = CssCode.hypergraph_product(base, base)
+    edges = css.x_stabs_binary().num_edges()
+    dec = CssDecoder(css, 0.01, 100)
+    dec.mc_run(0.01, NOISE_SEED, 1 << 40, 4096)
+    cnt = dec.mc_run(0.01, NOISE_SEED, 0, shots)
+    ms = ldpc_amd.last_kernel_ms()
+    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges / (ms * 1e-3) / 1e9
+    return {"workload": "configs[2]: CSS hypergraph-product code, 625 qubits (Hx, Hz 300 x 625, row weight 7), depolarizing "
+                        "p=0.01, BP f64 max 100 iterations on each half, logical failure test, %d shots" % shots,
+            "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<7,-4> (+ streamed tail)", "kernel_ms": ms,
+            "iterations_per_shot_both_halves": int(cnt[ldpc_amd.CNT_WORK]) / shots,
+            "logical_failures": int(cnt[ldpc_amd.CNT_FAILURES]),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+
+
 def bp_c5_line(shots=17664):
     """Secondary measurement: configs[4], (3,6)-regular n = 10^6 (3 GB of f64 messages per 64-shot group: the
     streamed BP form, one grid-wide kernel per phase).  Time = hipEvents around the whole host-driven loop."""
@@ -233,6 +256,7 @@ def main():
         if not args.no_bp and world == 1 and not use_bp:
             line["bp"] = bp_line(code)
             line["bp_c5"] = bp_c5_line()
+            line["css"] = css_line()
         if use_bp:
             # BP step: algorithmic bytes = 32 E per shot-iteration, iterations from the all-reduced counter
             alg = float(counters[ldpc_amd.CNT_WORK]) / world / args.steps * 32 * code.num_edges()
@@ -252,6 +276,7 @@ def main():
             line.pop("cpu_baseline", None)
             line.pop("bp", None)
             line.pop("bp_c5", None)
+            line.pop("css", None)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
