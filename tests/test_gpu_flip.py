@@ -46,7 +46,10 @@ def test_flip_mc_counters_c1_full():
                                                # 21 and 13 neighbours: two rounds per flip / 7-check records
                                                (3000, 2000, 4, 6, 0.03, 96), (3000, 1500, 2, 4, 0.04, 96),
                                                # weight far above the error list: piecewise set-up
-                                               (10000, 5000, 3, 6, 0.2, 24)])
+                                               (10000, 5000, 3, 6, 0.2, 24),
+                                               # largest sizes: near the LDS limit of the fast path (4 shots per wave), and
+                                               # the generic kernel near its own (one shot's state per wave, 125 of 160 KiB)
+                                               (60000, 30000, 3, 6, 0.01, 8), (400000, 200000, 3, 6, 0.005, 4)])
 def test_flip_matches_oracle(n, m, dv, dc, p, shots):
     code = LinearCode.random_regular_code(n, m, dv, dc, seed=1)
     oc = oracle_code(code)
