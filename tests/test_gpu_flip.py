@@ -133,3 +133,14 @@ def test_single_process_multi_device_runs_sum_to_the_single_run():
     assert (mc_run_multi(css, [0, 0], 0.05, 5, 0, 4000, "css", 30) == ref).all()
     with pytest.raises(Exception):
         mc_run_multi(code, [99], 0.04, 5, 0, 10, "flip")
+
+
+def test_flip_beyond_the_lds_limit_is_refused():
+    """A shot whose state (syndrome + two words of n bits) does not fit a CU's 160 KiB of LDS: LDPC_ERR_CAPACITY, no
+    launch (such codes are served by BP only)."""
+    import ldpc_amd
+    code = LinearCode.random_regular_code(1000000, 500000, 3, 6, seed=1)
+    dec = FlipDecoder(code)
+    with pytest.raises(ldpc_amd.LdpcError) as e:
+        dec.mc_run(0.01, SEED, 0, 4)
+    assert e.value.status == ldpc_amd.ERR_CAPACITY and "LDS" in str(e.value)
