@@ -105,6 +105,28 @@ def test_bp_extreme_priors():
             assert host_u64(dc)[i, 0] == c[0] and host_u32(di)[i] == it, (p, i)
 
 
+def test_bp_iteration_caps_zero_and_one():
+    """max_iterations = 0: the loop of belief_propagation.rs:26-29 never runs and the decision of the priors is
+    returned; 1: exactly one update.  Hamming code (persistent kernel) and C1 (a call this small runs the streamed
+    kernels unless forced), against the oracle."""
+    rng = np.random.default_rng(3)
+    for code, shots in ((LinearCode.hamming_code(), 8), (LinearCode.random_regular_code(1200, 900, 3, 4, seed=1), 40)):
+        n, m = code.len(), code.num_checks()
+        oc = oracle_code(code)
+        syn = np.stack([oc.syndrome_words(orc.sample_bsc_words(5, i, 0.03 if n > 7 else 0.2, n)) for i in range(shots)])
+        syn = syn.reshape(shots, max(nwords(m), 1))
+        for p in (0.03, 0.7):
+            for cap in (0, 1):
+                dec = BpDecoder(code, p, cap)
+                dc, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+                dec.correction_for_batch(shots, to_dev_u64(syn), dc, di)
+                gc, gi = host_u64(dc), host_u32(di)
+                for i in range(shots):
+                    c, it, _ = oc.bp_correction_for(p, cap, syn[i])
+                    assert (gc[i] == c).all() and gi[i] == it, (n, p, cap, i)
+                assert int(gi.max()) <= cap
+
+
 def test_bp_mc_counters_c1():
     g = np.load("tests/golden/c1_vectors.npz")
     code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
