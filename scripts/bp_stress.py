@@ -6,10 +6,11 @@ from ldpc_amd import BpDecoder, LinearCode, nwords
 from oracle import oracle as orc
 from tests.gpu_util import dev_f64, dev_u32, dev_u64, host_u32, host_u64, oracle_code, random_sparse_rows, to_dev_u64
 
-rng = np.random.default_rng(11)
+SEED_SHIFT = int(os.environ.get("LDPC_STRESS_SEED", "0"))   # other codes and noise per value
+rng = np.random.default_rng(11 + SEED_SHIFT)
 cases = []
 for (n, m, dv, dc) in [(2000, 1000, 5, 10), (2400, 1200, 4, 8), (1500, 900, 3, 5), (3000, 2500, 5, 6), (640, 320, 3, 6), (6400, 3200, 3, 6)]:
-    cases.append(("reg(%d,%d) n=%d" % (dv, dc, n), LinearCode.random_regular_code(n, m, dv, dc, seed=3)))
+    cases.append(("reg(%d,%d) n=%d" % (dv, dc, n), LinearCode.random_regular_code(n, m, dv, dc, seed=3 + SEED_SHIFT)))
 for (n, m, maxdeg) in [(2000, 1200, 10), (900, 700, 14), (5000, 2000, 5)]:
     cases.append(("irregular n=%d m=%d deg<=%d" % (n, m, maxdeg), LinearCode.from_parity_check_matrix(n, random_sparse_rows(rng, n, m, maxdeg))))
 bad = 0
@@ -22,7 +23,7 @@ for name, code in cases:
             shots = int(sys.argv[1]) if len(sys.argv) > 1 else 96
             syn = np.zeros((shots, max(nwords(m), 1)), dtype=np.uint64)
             for i in range(shots):
-                syn[i, : nwords(m)] = oc.syndrome_words(orc.sample_bsc_words(4, i, p, n))
+                syn[i, : nwords(m)] = oc.syndrome_words(orc.sample_bsc_words(4 + SEED_SHIFT, i, p, n))
             dec = BpDecoder(code, p, cap)
             dc_, di, dp = dev_u64((shots, nwords(n))), dev_u32((shots,)), dev_f64((shots, n))
             dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di, dp)
