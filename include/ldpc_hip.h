@@ -79,6 +79,11 @@ int ldpc_set_stream(void *hip_stream);
 /* Duration of the decoding kernels of the most recent call on this thread,
  * measured with hipEvents on the launch stream (bench.py roofline). */
 double ldpc_last_kernel_ms(void);
+/* The LDPC_HIP_* environment variables (A/B, test and profiling switches; none is needed in production) are read
+ * once, when the library first needs one.  A test that changes one afterwards calls this to have them read again.
+ * No counterpart in the reference (it has no configuration).  Not to be called while other
+ * threads are inside decoding calls. */
+void ldpc_debug_reload_switches(void);
 
 /* ---- LinearCode (codes/linear_code/mod.rs) ----------------------------- */
 /* SparseBinMat::new(n_bits, rows) + LinearCode::from_parity_check_matrix

@@ -70,6 +70,7 @@ def lib():
         "ldpc_set_device": (i, [i]),
         "ldpc_set_stream": (i, [vp]),
         "ldpc_last_kernel_ms": (dbl, []),
+        "ldpc_debug_reload_switches": (None, []),
         "ldpc_code_create": (i, [sz, sz, vp, vp, pp]),
         "ldpc_code_hamming": (i, [pp]),
         "ldpc_code_repetition": (i, [sz, pp]),
@@ -181,6 +182,11 @@ def set_device(device):
 
 def last_kernel_ms():
     return float(lib().ldpc_last_kernel_ms())
+
+
+def reload_switches():
+    """The library reads its LDPC_HIP_* diagnostic switches once; call this after changing one (tests, A/B scripts)."""
+    lib().ldpc_debug_reload_switches()
 
 
 class Probability:

@@ -216,7 +216,10 @@ struct ldpc_flip_decoder {
     std::mutex io_mu;               // single-vector staging, as in ldpc_code
     DeviceBuffer io_in, io_out;
     NbTable nbt{};
-    int path = 0;   // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel
+    Nb3Table nbt3{};
+    // 0 = undecided, 1 = CSR kernel (one wave per shot), 2 = neighbourhood-table kernel (flip2_kernel),
+    // 3 = eight shots per wave (flip3_kernel: regular codes of bit degree 3, n < 16384)
+    int path = 0;
 };
 
 struct ldpc_bp_decoder {
@@ -324,6 +327,45 @@ bool build_nb_table(const LinearCode &c, std::vector<uint32_t> &out, uint32_t &k
     return true;
 }
 
+// Table of flip3_kernel (kernels.hpp Nb3Table).  Returns false when the code does not suit it.
+bool build_nb3_table(const LinearCode &c, std::vector<uint32_t> &out, Nb3Table &tab)
+{
+    const SparseBinMat &h = c.h, &t = c.ht;
+    const uint32_t n = h.ncols, m = h.nrows();
+    if (n == 0 || m == 0 || n + 512 > 32 * 512) return false;
+    for (uint32_t b = 0; b < n; b++)
+        if (t.row_len(b) != 3) return false;
+    tab.sw = (m + 64) / 64;
+    tab.windows = (n + 512) / 512;
+    const uint32_t spare_bit = tab.windows * 512 - 1, spare_chk = m;
+    auto pack = [](uint32_t i) { return ((i >> 5) * 4u) << 16 | (i & 31u); };
+    out.assign((size_t)(n + 1) * 16 * 4, 0);
+    for (size_t s = 0; s < (size_t)(n + 1) * 16; s++) {
+        out[s * 4] = pack(spare_bit);
+        out[s * 4 + 1] = out[s * 4 + 2] = out[s * 4 + 3] = pack(spare_chk);
+    }
+    std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
+    for (uint32_t b = 0; b < n; b++) {
+        size_t slot = 0;
+        auto put = [&](uint32_t bit) {
+            uint32_t *r = &out[((size_t)b * 16 + slot++) * 4];
+            r[0] = pack(bit);
+            for (uint32_t k = 0; k < 3; k++) r[1 + k] = pack(t.idx[t.ptr[bit] + k]);
+        };
+        stamp[b] = b;
+        put(b);
+        for (uint32_t k = t.ptr[b]; k < t.ptr[b + 1]; k++)
+            for (uint32_t e = h.ptr[t.idx[k]]; e < h.ptr[t.idx[k] + 1]; e++) {
+                const uint32_t bb = h.idx[e];
+                if (stamp[bb] == b) continue;
+                if (slot == 16) return false;   // more than 15 neighbours
+                stamp[bb] = b;
+                put(bb);
+            }
+    }
+    return true;
+}
+
 int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
 {
     int st = dec->code.ensure_device();
@@ -332,16 +374,23 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
     st = zero_counters(dec->counters);
     if (st) return st;
     a.counters = dec->counters.as<unsigned long long>();
-    a.max_flips = 0xFFFFFFFFu;
-    if (const char *mf = std::getenv("LDPC_HIP_FLIP_MAXFLIPS")) a.max_flips = (uint32_t)std::strtoul(mf, nullptr, 10);   // profiling aid
+    a.max_flips = switches().flip_maxflips;   // profiling aid
     const DeviceGraph &g = dec->code.dg;
+    // (the choice of kernel is made once per handle; LDPC_HIP_FLIP_KERNEL = "csr" / "v2" forces the older forms: tests)
     if (dec->path == 0) {
         dec->path = 1;
         std::vector<uint32_t> tab;
         uint32_t kshift = 0, dvp = 0;
-        const char *force = std::getenv("LDPC_HIP_FLIP_KERNEL");   // "csr" forces the generic kernel (tests)
-        const bool allow_fast = !(force && std::strcmp(force, "csr") == 0);
-        if (allow_fast && flip2_lds_bytes(g, 16, 1024) <= 64 * 1024 && g.n < (1u << 26) &&
+        const bool allow_fast = switches().flip_kernel != 1;
+        Nb3Table t3{};
+        if (allow_fast && switches().flip_kernel != 2 && build_nb3_table(dec->code.host, tab, t3) &&
+            flip3_lds_bytes(t3, 1024) <= 64 * 1024) {
+            HIP_TRY(dec->nb.reserve(tab.size() * 4));
+            HIP_TRY(hipMemcpy(dec->nb.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            t3.rec = dec->nb.as<uint4>();
+            dec->nbt3 = t3;
+            dec->path = 3;
+        } else if (allow_fast && flip2_lds_bytes(g, 16, 1024) <= 64 * 1024 && g.n < (1u << 26) &&
             build_nb_table(dec->code.host, tab, kshift, dvp)) {
             HIP_TRY(dec->nb.reserve(std::max<size_t>(tab.size(), 1) * 4));
             if (!tab.empty()) HIP_TRY(hipMemcpy(dec->nb.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
@@ -357,17 +406,20 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
             dec->path = 2;
         }
     }
-    if (dec->path == 2) {
+    if (dec->path == 2 || dec->path == 3) {
+        const size_t max_blocks = dec->path == 3 ? flip3_max_blocks() : flip2_max_blocks(g);
         if (!a.errors_out) {
-            HIP_TRY(dec->o_scratch.reserve((size_t)flip2_max_blocks(g) * 8 * std::max<size_t>(words_for(g.n), 1) * 8));
+            HIP_TRY(dec->o_scratch.reserve(max_blocks * 8 * std::max<size_t>(words_for(g.n), 1) * 8));
             a.o_scratch = dec->o_scratch.as<uint64_t>();
         }
         a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
-        if (!a.list_cap) a.list_cap = 512;   // given words: weight unknown
-        HIP_TRY(dec->flip_log.reserve((size_t)flip2_max_blocks(g) * 8 * a.flip_log_cap * 4));
+        if (dec->path == 3) a.list_cap = a.list_cap ? flip3_list_cap(a.expected_weight) : 512;   // given words: weight unknown
+        else if (!a.list_cap) a.list_cap = 512;
+        HIP_TRY(dec->flip_log.reserve(max_blocks * 8 * a.flip_log_cap * 4));
         a.flip_log = dec->flip_log.as<uint32_t>();
         KernelTimer timer;
-        HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
+        if (dec->path == 3) HIP_TRY(launch_flip3(g, dec->nbt3, a, switches().flip_prof, g_stream));
+        else HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
         timer.stop_and_store();
         if (counters_out) return read_counters(dec->counters, counters_out);
         HIP_TRY(hipStreamSynchronize(g_stream));
@@ -426,10 +478,9 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // (E = 2100 per half) all run fastest with 8 waves per group: shorter iterations, shorter straggler tail
     const uint32_t waves_default = g.E <= 256 ? 1u : g.E <= 1024 ? 2u : 8u;
     uint32_t waves = waves_default;
-    if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) waves = (uint32_t)std::max(1, std::min(8, std::atoi(e)));   // A/B aid
+    if (switches().bp_waves) waves = (uint32_t)switches().bp_waves;   // A/B aid
     // only as many groups as are resident at once: a queued workgroup would find the shot queue drained
-    uint64_t over = 1;
-    if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) over = (uint64_t)std::max(1, std::atoi(e));   // A/B aid
+    const uint64_t over = (uint64_t)switches().bp_oversub;   // A/B aid
     uint64_t max_groups = std::min<uint64_t>(std::max<uint64_t>(over * bp_resident_groups(waves, dec->reg_dc, dec->reg_dv) / r.share, 1),
                                              budget / std::max<size_t>(per_group, 1) / r.share);
     if (max_groups == 0)
@@ -448,14 +499,12 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     const uint64_t by_memory = budget / std::max<size_t>(per_group, 1);
     const uint64_t work_groups = (r.n_shots + 63) / 64;
     bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256) || (g.E >= 200 && work_groups <= 128);
-    if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) {   // A/B and test aid
-        if (!std::strcmp(e, "stream")) stream = true;
-        else if (!std::strcmp(e, "persistent")) stream = false;
-    }
+    if (switches().bp_path == 1) stream = true;   // A/B and test aid
+    else if (switches().bp_path == 2) stream = false;
     if (stream) groups = std::min<uint64_t>(std::min<uint64_t>(by_memory, 4096), std::max<uint64_t>((r.n_shots + 63) / 64, 1));
-    if (const char *e = std::getenv("LDPC_HIP_BP_GROUPS"))   // A/B aid (streamed form only: the persistent grid must stay resident)
-        if (stream) groups = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)std::atoll(e)));
-    if (std::getenv("LDPC_HIP_DEBUG"))
+    if (switches().bp_groups && stream)   // A/B aid (streamed form only: the persistent grid must stay resident)
+        groups = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)switches().bp_groups));
+    if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
     HIP_TRY(dec->workspace.reserve(per_group * groups));
@@ -466,7 +515,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.xor_input = r.xor_input;
     a.max_iter = dec->max_iter;
     a.fail_bit = r.fail_bit;
-    a.profile = std::getenv("LDPC_HIP_BP_PROFILE") != nullptr;
+    a.profile = switches().bp_profile;
     a.prior = std::log((1.0 - dec->p) / dec->p);   // belief_propagation.rs:38
     a.seed = r.seed;
     a.first_shot = r.first_shot;
@@ -504,16 +553,15 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
         uint64_t rounds = 0;
         HIP_TRY(bp_stream_run(g, a, dec->stream_state.as<char>(), (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds));
-        if (std::getenv("LDPC_HIP_DEBUG")) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu rounds\n", (unsigned long long)rounds);
+        if (switches().debug) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu rounds\n", (unsigned long long)rounds);
     } else {
         // tail hand-off (kernels.hpp, BpArgs::handoff_iter): shots still running 16 iterations after the queue
         // has drained are finished by the streamed form, the whole chip on the few groups that hold them
-        uint32_t handoff = 16;
-        if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) handoff = (uint32_t)std::strtoul(e, nullptr, 10);   // 0 = off
+        uint32_t handoff = switches().bp_handoff;   // LDPC_HIP_BP_HANDOFF: 0 = off
         // (the streamed tail packs the stragglers of all groups into few (bps_compact), which the persistent
         // kernel cannot do, and a streamed iteration of a small tail costs about 0.05 ms of launches: below
         // E = 200 a lone group's persistent iteration is cheaper than that; scripts/bp_small_batch.py)
-        const bool forced = std::getenv("LDPC_HIP_BP_HANDOFF") != nullptr;
+        const bool forced = switches().bp_handoff_set;
         if (handoff == 0 || dec->max_iter <= handoff || (!forced && g.E < 200)) handoff = 0xFFFFFFFFu;
         a.handoff_iter = handoff;
         if (handoff != 0xFFFFFFFFu) {
@@ -532,7 +580,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
                 const auto t1 = std::chrono::steady_clock::now();
                 uint64_t rounds = 0;
                 HIP_TRY(bp_stream_run(g, a, dec->stream_state.p, (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds, true));
-                if (std::getenv("LDPC_HIP_DEBUG"))
+                if (switches().debug)
                     std::fprintf(stderr, "[ldpc_hip] bp tail hand-off: persistent kernel %.2f ms, then %llu streamed rounds in %.2f ms\n",
                                  std::chrono::duration<double, std::milli>(t1 - t0).count(), (unsigned long long)rounds,
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -606,6 +654,8 @@ try {
 LDPC_CATCH
 
 double ldpc_last_kernel_ms(void) { return g_last_ms; }
+
+void ldpc_debug_reload_switches(void) { reload_switches(); }
 
 // ---- LinearCode -----------------------------------------------------------
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
@@ -1032,7 +1082,8 @@ try {
     a.synd_out = d_syndromes_out;
     a.words_out = d_words_out;
     a.gap = make_gap_table(probability);
-    a.list_cap = flip2_list_cap((double)dec->code.host.len() * probability);   // error list sized for the channel
+    a.expected_weight = (double)dec->code.host.len() * probability;
+    a.list_cap = flip2_list_cap(a.expected_weight);   // error list sized for the channel
     return run_flip(dec, a, counters);
 }
 LDPC_CATCH
@@ -1434,7 +1485,7 @@ try {
     // 1000 shots of the 625-qubit code 13.7 -> 7.3 ms.  Large runs do not: two persistent kernels on two streams were
     // seen to run one after the other, each on half of the workgroup slots (8.4e6 shots: 1.24 -> 1.65 s).
     bool side_by_side = n_shots <= 128 * 64;
-    if (const char *e = std::getenv("LDPC_HIP_CSS_SIDE_BY_SIDE")) side_by_side = std::atoi(e) != 0;   // A/B and test aid
+    if (switches().css_side_by_side >= 0) side_by_side = switches().css_side_by_side != 0;   // A/B and test aid
     for (size_t done = 0; done < n_shots;) {
         size_t chunk = std::min(chunk_max, n_shots - done);
         HIP_TRY(dec->flags.reserve(chunk));

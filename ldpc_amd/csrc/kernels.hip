@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "bp_math.hpp"
@@ -670,6 +672,312 @@ template <int DVP, int G, bool REG, bool DIAG, bool ONE, bool SMALL> __global__ 
         if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
     }
     if (DIAG && a.counters && gl == 0 && c_iters) atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_iters);
+}
+
+// ---------------------------------------------------------------------------
+// Flip decoder, third form: regular codes of bit degree 3 whose neighbourhoods
+// fit 16 slots and whose flippable mask fits 32 windows of 512 bits (C1, C2).
+// One wave carries EIGHT shots, 8 lanes each, every lane working two slots of
+// the flipped bit's neighbourhood row, and the loop body is branch-free:
+//   * the summary of the flippable mask F is one 32-bit word per shot kept in
+//     registers (bit w = window w of F may hold a flippable bit), so finding the
+//     lowest flippable bit is one 64-byte LDS read per shot and a DPP minimum;
+//   * a slot's F bit is written with ds_mskor (clear-then-set in one LDS
+//     operation, no read, no compare, no divergent or/and);
+//   * padding slots and the rounds of a shot that has nothing left to flip
+//     point at a spare check that is never set and a spare mask bit that is
+//     never scanned, so they need no predication.
+// Same decisions as flip.rs:21-43: F is exact after every flip and its lowest
+// set bit is flipped next.
+// ---------------------------------------------------------------------------
+__device__ inline uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// LDS: mem = (mem & ~mask) | data in one operation
+__device__ inline void lds_mskor(uint32_t addr, uint32_t mask, uint32_t data)
+{
+    asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(addr), "v"(mask), "v"(data) : "memory");
+}
+
+// minimum over each group of 8 lanes, DPP folded into the v_min (every source lane is in range: bound_ctrl is moot)
+__device__ inline uint32_t half_row_min2_u32(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v = o < v ? o : v;
+    return v;
+}
+
+__device__ inline uint32_t half_row_add_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
+    return v;
+}
+
+__device__ inline uint32_t half_row_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return v;
+}
+
+// unsatisfied checks of a record >= 2 (bit degree 3: flip.rs:41 `> deg / 2`)
+__device__ inline bool rec3_flippable(const uint4 &r, const char *S)
+{
+    const uint32_t w0 = *(const uint32_t *)(S + (r.y >> 16)), w1 = *(const uint32_t *)(S + (r.z >> 16)),
+                   w2 = *(const uint32_t *)(S + (r.w >> 16));
+    const uint32_t u = ((w0 >> (r.y & 31)) & 1u) + ((w1 >> (r.z & 31)) & 1u) + ((w2 >> (r.w & 31)) & 1u);
+    return u >= 2;
+}
+
+__host__ __device__ constexpr uint32_t flip3_hdr_words(uint32_t list_cap) { return 33 + list_cap / 4 + 1; }
+
+template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    constexpr uint32_t SPW = 8;                      // shots per wave, 8 lanes each
+    const uint32_t lane = threadIdx.x, grp = lane >> 3, gl = lane & 7;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    const uint32_t Sw = nbt.sw, windows = nbt.windows, Fw = windows * 8;
+    const uint32_t per_shot = Sw + Fw;               // LDS words per shot: S (with the spare check), F in whole windows
+    uint32_t *q = (uint32_t *)lds;
+    uint16_t *list = (uint16_t *)(lds + 33);         // error positions of the shot being set up
+    const uint32_t LIST_CAP = a.list_cap;
+    uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 4);
+    uint64_t *state = lds + flip3_hdr_words(LIST_CAP);
+    const uint4 *nb = nbt.rec;
+    const uint32_t dummy_row = g.n;
+
+    for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
+    wave_sync();
+
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+    unsigned long long t_setup = 0, t_loop = 0, t_out = 0, n_iter = 0;
+
+    for (uint64_t base = (uint64_t)blockIdx.x * SPW; base < a.n_shots; base += (uint64_t)gridDim.x * SPW) {
+        const uint32_t nvalid = a.n_shots - base < SPW ? (uint32_t)(a.n_shots - base) : SPW;
+        unsigned long long t0 = 0;
+        if (PROF) t0 = __builtin_amdgcn_s_memtime();
+        auto err_words = [&](uint32_t j) -> uint64_t * {
+            return a.errors_out ? a.errors_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * SPW + j) * Wn;
+        };
+        // ------------------------------------------------------------------ set-up, wave-wide, shot by shot
+        for (uint32_t j = 0; j < nvalid; j++) {
+            uint64_t *S = state + (size_t)j * per_shot, *F = S + Sw, *O = err_words(j);
+            char *Sc = (char *)S, *Fc = (char *)F;
+            const uint64_t i = base + j, shot = a.first_shot + i;
+            for (uint32_t w = lane; w < per_shot; w += 64) S[w] = 0;
+            if (lane == 0) *cnt_lds = 0;
+            wave_order();
+            for (uint32_t w = lane; w < Wn; w += 64) {
+                const uint32_t nb_bits = bits_in_word(g.n, w);
+                uint64_t x;
+                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
+                else {
+                    x = a.words_in[i * Wn + w];
+                    if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
+                }
+                O[w] = x;
+                const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+                if (cc) {
+                    uint32_t off = atomicAdd(cnt_lds, cc);
+                    while (x) {
+                        if (off < LIST_CAP) list[off] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
+                        off++;
+                        x &= x - 1;
+                    }
+                }
+            }
+            wave_sync();   // O is read back from memory below (overflow path) and at the end
+            const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
+            if (total <= LIST_CAP) {
+                // pass 1, syndrome: toggle the three checks of every error bit (slot 0 of its row)
+                for (uint32_t t0i = lane; t0i < total; t0i += 64 * 4) {
+                    uint4 r[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        if (t0i + 64 * u < total) r[u] = nb[(size_t)list[t0i + 64 * u] << 4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        if (t0i + 64 * u < total) {
+                            atomicXor((uint32_t *)(Sc + (r[u].y >> 16)), 1u << (r[u].y & 31));
+                            atomicXor((uint32_t *)(Sc + (r[u].z >> 16)), 1u << (r[u].z & 31));
+                            atomicXor((uint32_t *)(Sc + (r[u].w >> 16)), 1u << (r[u].w & 31));
+                        }
+                }
+                wave_order();
+                // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
+                // slot reads the spare check and is never flippable
+                constexpr uint32_t P2 = 8;
+                const uint32_t slots = total << 4;
+                for (uint32_t t0i = lane; t0i < slots; t0i += 64 * P2) {
+                    uint4 r[P2];
+#pragma unroll
+                    for (uint32_t u = 0; u < P2; u++) {
+                        const uint32_t t = t0i + 64 * u;
+                        r[u] = nb[((size_t)(t < slots ? list[t >> 4] : dummy_row) << 4) + (t & 15)];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < P2; u++)
+                        if (rec3_flippable(r[u], Sc)) atomicOr((uint32_t *)(Fc + (r[u].x >> 16)), 1u << (r[u].x & 31));
+                }
+            } else {
+                // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words
+                const uint32_t pw = LIST_CAP / 64;
+                for (int pass = 0; pass < 2; pass++) {
+                    for (uint32_t wb = 0; wb < Wn; wb += pw) {
+                        wave_order();
+                        if (lane == 0) *cnt_lds = 0;
+                        wave_order();
+                        const uint32_t w = wb + lane;
+                        uint64_t x = (lane < pw && w < Wn) ? O[w] : 0;
+                        const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+                        if (cc) {
+                            uint32_t off = atomicAdd(cnt_lds, cc);
+                            while (x) {
+                                list[off++] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
+                                x &= x - 1;
+                            }
+                        }
+                        wave_order();
+                        const uint32_t cnt = __builtin_amdgcn_readfirstlane(*cnt_lds);
+                        if (pass == 0) {
+                            for (uint32_t t = lane; t < cnt; t += 64) {
+                                const uint4 r = nb[(size_t)list[t] << 4];
+                                atomicXor((uint32_t *)(Sc + (r.y >> 16)), 1u << (r.y & 31));
+                                atomicXor((uint32_t *)(Sc + (r.z >> 16)), 1u << (r.z & 31));
+                                atomicXor((uint32_t *)(Sc + (r.w >> 16)), 1u << (r.w & 31));
+                            }
+                        } else {
+                            for (uint32_t t = lane; t < (cnt << 4); t += 64) {
+                                const uint4 r = nb[((size_t)list[t >> 4] << 4) + (t & 15)];
+                                if (rec3_flippable(r, Sc)) atomicOr((uint32_t *)(Fc + (r.x >> 16)), 1u << (r.x & 31));
+                            }
+                        }
+                    }
+                    wave_order();
+                }
+            }
+            wave_order();
+            if (a.synd_out)
+                for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+        }
+        unsigned long long t1 = 0;
+        if (PROF) t1 = __builtin_amdgcn_s_memtime();
+        // ------------------------------------------------------------------ serial flips, 8 shots in lockstep
+        uint32_t nfl = 0;
+        {
+            char *Sg = (char *)(state + (size_t)grp * per_shot), *Fg = Sg + (size_t)Sw * 8;
+            const uint32_t Fg_addr = lds_addr_of(Fg);
+            uint32_t *flog = a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;
+            const uint4 *nbl = nb + gl * 2;            // the lane's two slots of a row
+            // summary of F: bit w = window w holds a flippable bit
+            uint32_t fs2 = 0;
+            for (uint32_t w = 0; w < windows; w++) {
+                const uint64_t x = *(const uint64_t *)(Fg + (w << 6) + gl * 8);
+                fs2 |= (x != 0 ? 1u : 0u) << w;
+            }
+            fs2 = half_row_or_u32(fs2);
+            if (grp >= nvalid) fs2 = 0;
+            // every iteration flips a bit (at most m flips: each lowers the syndrome weight) or retires a window
+            const uint32_t iter_cap = g.m + 33 * (g.m + 2) + 64;
+            for (uint32_t it = 0; it < iter_cap; it++) {
+                if (!__ballot(fs2 != 0)) break;                            // flip.rs:27 find_flippable == None, all shots
+                const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
+                const uint64_t x = *(const uint64_t *)(Fg + (w2 << 6) + gl * 8);
+                const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+                // lowest set bit of the lane's 64 mask bits; all ones when there is none
+                const uint32_t clo = lo ? (uint32_t)__builtin_ctz(lo) : NONE, chi = hi ? (uint32_t)__builtin_ctz(hi) | 32u : NONE;
+                const uint32_t c = (clo < chi ? clo : chi) | (gl << 6);
+                const uint32_t mpos = half_row_min2_u32(c);
+                const bool found = fs2 != 0 && mpos != NONE;
+                // the window is empty, or the bit about to be flipped is its only one: retire it (a neighbour that
+                // becomes flippable in it sets the summary bit again below)
+                const uint32_t inwin = half_row_add_u32((uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi));
+                if (inwin <= 1) fs2 &= fs2 - 1;
+                const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
+                const uint4 r0 = nbl[(size_t)b << 4], r1 = nbl[((size_t)b << 4) + 1];
+                const uint32_t one = found ? 1u : 0u;
+                if (gl == 0) {                                             // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
+                    atomicXor((uint32_t *)(Sg + (r0.y >> 16)), one << (r0.y & 31));
+                    atomicXor((uint32_t *)(Sg + (r0.z >> 16)), one << (r0.z & 31));
+                    atomicXor((uint32_t *)(Sg + (r0.w >> 16)), one << (r0.w & 31));
+                    flog[nfl] = b;                                         // output ^= e_b (flip.rs:30) is deferred: log the flip
+                }
+                wave_order();
+                // both slots re-evaluate their bit against the new syndrome and rewrite its F bit
+                const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
+                const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
+                lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
+                lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
+                const uint32_t contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
+                fs2 |= half_row_or_u32(contrib);
+                nfl += one;
+                wave_order();
+                if (PROF) n_iter++;
+            }
+        }
+        wave_sync();   // log entries are in memory
+        unsigned long long t2 = 0;
+        if (PROF) t2 = __builtin_amdgcn_s_memtime();
+        // ---------------------------------------------------------------- failure test + outputs
+        for (uint32_t j = 0; j < nvalid; j++) {
+            uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Sw;   // F is dead: rebuild the word there
+            uint32_t *O32 = (uint32_t *)Oj;
+            const uint64_t *Ej = err_words(j);
+            const uint32_t *lj = a.flip_log + ((size_t)blockIdx.x * SPW + j) * a.flip_log_cap;
+            const uint64_t i = base + j;
+            const uint32_t nfj = __shfl(nfl, j * 8, 64), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
+            for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&Ej[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_order();
+            for (uint32_t t0i = lane; t0i < nf; t0i += 64 * 4) {
+                uint32_t bb[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                    bb[u] = t0i + 64 * u < nf ? __hip_atomic_load(&lj[t0i + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                    if (bb[u] != NONE) atomicXor(&O32[bb[u] >> 5], 1u << (bb[u] & 31));                // flip.rs:30
+            }
+            wave_order();
+            uint64_t anyo = 0, anys = 0;
+            for (uint32_t w = lane; w < Wn; w += 64) {
+                const uint64_t x = Oj[w];
+                anyo |= x;
+                if (a.words_out) a.words_out[i * Wn + w] = x;
+            }
+            for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
+            const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
+            if (a.flips_out && lane == 0) a.flips_out[i] = nf;
+            c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nf;
+        }
+        wave_sync();
+        if (PROF) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            t_setup += t1 - t0; t_loop += t2 - t1; t_out += t3 - t2;
+        }
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+        if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
+        if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+        if (PROF) {   // diagnostics (LDPC_HIP_FLIP_PROF): wave iterations, cycles in the loop, cycles in set-up + output
+            atomicAdd(&a.counters[CNT_CAPPED], n_iter);
+            atomicAdd(&a.counters[CNT_XFAIL], t_loop);
+            atomicAdd(&a.counters[CNT_ZFAIL], t_setup + t_out);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1744,8 +2052,7 @@ uint32_t flip2_lanes_per_shot(const DeviceGraph &g)
 {
     // 8 lanes per shot (8 shots per wave) halves the instructions per shot; needs 8 states in LDS
     // (measured at C2: 16 lanes x 4 shots beats 8 x 8: one round per flip, twice the waves in flight)
-    if (const char *e = std::getenv("LDPC_HIP_FLIP_LANES")) return std::atoi(e) == 8 ? 8u : 16u;   // A/B aid
-    return 16u;
+    return (uint32_t)switches().flip_lanes;   // A/B aid (LDPC_HIP_FLIP_LANES)
 }
 
 // list capacity for an expected error weight: the next power of two above mean + 4 sigma, within [64, 1024]
@@ -1761,7 +2068,7 @@ static uint32_t flip2_blocks_for(const DeviceGraph &g, uint32_t list_cap)
 {
     // one wave per block; blocks per CU limited by LDS (160 KiB) and by 8 waves per SIMD
     const uint32_t lanes = flip2_lanes_per_shot(g);
-    return 256u * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g, lanes, list_cap));
+    return device_cu_count() * (uint32_t)std::min<size_t>(32, (160 * 1024) / flip2_lds_bytes(g, lanes, list_cap));
 }
 
 // upper bound on the blocks of any launch (scratch sizing): the smallest list
@@ -1803,6 +2110,96 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
         if (lanes == 8) launch_flip2_t<7, 8>(g, nb, a, grid, lds, st);
         else launch_flip2_t<7, 16>(g, nb, a, grid, lds, st);
     }
+    return hipGetLastError();
+}
+
+namespace {
+Switches g_switches;
+std::once_flag g_switches_once;
+Switches read_switches()
+{
+    Switches s;
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_KERNEL")) s.flip_kernel = !std::strcmp(e, "csr") ? 1 : !std::strcmp(e, "v2") ? 2 : 0;
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_MAXFLIPS")) s.flip_maxflips = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_LANES")) s.flip_lanes = std::atoi(e) == 8 ? 8 : 16;
+    s.flip_prof = std::getenv("LDPC_HIP_FLIP_PROF") != nullptr;
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_BPC")) s.flip_bpc = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) s.bp_waves = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) s.bp_oversub = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) s.bp_path = !std::strcmp(e, "stream") ? 1 : !std::strcmp(e, "persistent") ? 2 : 0;
+    if (const char *e = std::getenv("LDPC_HIP_BP_GROUPS")) s.bp_groups = std::max(1ll, std::atoll(e));
+    if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) {
+        s.bp_handoff_set = true;
+        s.bp_handoff = (uint32_t)std::strtoul(e, nullptr, 10);
+    }
+    s.bp_profile = std::getenv("LDPC_HIP_BP_PROFILE") != nullptr;
+    s.bp_stream_skew = std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
+    if (const char *e = std::getenv("LDPC_HIP_BP_TAIL_BURST")) s.bp_tail_burst = std::max(1, std::atoi(e));
+    s.bp_no_compact = std::getenv("LDPC_HIP_BP_NO_COMPACT") != nullptr;
+    if (const char *e = std::getenv("LDPC_HIP_CSS_SIDE_BY_SIDE")) s.css_side_by_side = std::atoi(e) != 0 ? 1 : 0;
+    s.debug = std::getenv("LDPC_HIP_DEBUG") != nullptr;
+    return s;
+}
+}  // namespace
+
+const Switches &switches()
+{
+    std::call_once(g_switches_once, [] { g_switches = read_switches(); });
+    return g_switches;
+}
+
+void reload_switches()
+{
+    (void)switches();
+    g_switches = read_switches();
+}
+
+// multiprocessors of the current device (cached per device index)
+uint32_t device_cu_count()
+{
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return (uint32_t)cached[dev];
+}
+
+size_t flip3_lds_bytes(const Nb3Table &t, uint32_t list_cap)
+{
+    return ((size_t)flip3_hdr_words(list_cap) + 8 * ((size_t)t.sw + (size_t)t.windows * 8)) * 8;
+}
+
+// list capacity for an expected error weight: mean + 4 sigma, in steps of 64 within [64, 1024]
+uint32_t flip3_list_cap(double expected_weight)
+{
+    const double want = expected_weight + 4.0 * std::sqrt(expected_weight > 0 ? expected_weight : 0.0) + 8.0;
+    uint32_t cap = 64;
+    while (cap < 1024 && (double)cap < want) cap += 64;
+    return cap;
+}
+
+// upper bound on the blocks of any flip3 launch (scratch sizing): 8 one-wave blocks per SIMD
+uint32_t flip3_max_blocks() { return device_cu_count() * 32u; }
+
+hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    const size_t lds = flip3_lds_bytes(nb, a.list_cap);
+    if (lds > 64 * 1024 || a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(32, (160 * 1024) / lds);
+    if (switches().flip_bpc) per_cu = std::min<uint32_t>(per_cu, (uint32_t)switches().flip_bpc);
+    if (switches().debug) {
+        int occ = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)flip3_kernel<false>, 64, lds);
+        std::fprintf(stderr, "[ldpc_hip] flip3: lds %zu B, %u blocks per CU (occupancy API: %d)\n", lds, per_cu, occ);
+    }
+    const uint32_t grid = grid_for(a.n_shots, 8, device_cu_count() * per_cu);
+    if (prof) hipLaunchKernelGGL(flip3_kernel<true>, dim3(grid), dim3(64), lds, st, g, nb, a);
+    else hipLaunchKernelGGL(flip3_kernel<false>, dim3(grid), dim3(64), lds, st, g, nb, a);
     return hipGetLastError();
 }
 
@@ -1887,7 +2284,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     // two sets of groups half an iteration apart (see bps_iterate); a single group runs alone
     // Measured at C5: no gain from the skew (a check-update wave keeps its SIMD only 22 % busy, so the check update
     // needs all four wave slots of a SIMD to itself); one set by default, LDPC_HIP_BP_STREAM_SKEW=1 for experiments
-    const bool skew = !resume && std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
+    const bool skew = !resume && switches().bp_stream_skew;
     uint32_t set0[2] = {0, skew ? (groups + 1) / 2 : groups}, setn[2] = {skew ? (groups + 1) / 2 : groups, skew ? groups / 2 : 0};
     unsigned long long alive[2] = {0, 0};
     bool wants_checks[2] = {true, true};
@@ -1897,7 +2294,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     // have stopped meanwhile do nothing (stopped slots are harvested once and leave the active mask; groups
     // without active slots return at once), and a round of a small tail costs less than the sync.
     uint32_t burst = 4, since_sync = 0;
-    if (const char *ev = std::getenv("LDPC_HIP_BP_TAIL_BURST")) burst = (uint32_t)std::max(1, std::atoi(ev));   // A/B aid
+    if (switches().bp_tail_burst) burst = (uint32_t)switches().bp_tail_burst;   // A/B aid
     auto control = [&](int t) -> hipError_t {
         const dim3 grid(setn[t] * parts), ctl(setn[t]);
         const uint32_t g0 = set0[t];
@@ -1983,7 +2380,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         compactions++;
         return hipGetLastError();
     };
-    const bool may_compact = !skew && std::getenv("LDPC_HIP_BP_NO_COMPACT") == nullptr;   // (A/B and test aid)
+    const bool may_compact = !skew && !switches().bp_no_compact;   // (A/B and test aid)
     for (int t = 0; t < 2; t++)
         if (setn[t] && (e = control(t)) != hipSuccess) return e;
     if (resume && alive[0]) {
@@ -2032,7 +2429,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (rounds_out) *rounds_out = rounds;
-    if (std::getenv("LDPC_HIP_DEBUG") && compactions) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu tail compactions\n", (unsigned long long)compactions);
+    if (switches().debug && compactions) std::fprintf(stderr, "[ldpc_hip] bp stream: %llu tail compactions\n", (unsigned long long)compactions);
     return hipGetLastError();
 }
 

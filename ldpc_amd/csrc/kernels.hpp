@@ -9,6 +9,31 @@
 
 namespace ldpc {
 
+// Diagnostic switches (the LDPC_HIP_* environment variables: A/B, test and profiling aids, never needed in
+// production).  The environment is read ONCE, when the library first needs a switch; a test that changes a variable
+// afterwards calls ldpc_debug_reload_switches() (not meant to run beside decoding calls of other threads).
+struct Switches {
+    int flip_kernel = 0;              // LDPC_HIP_FLIP_KERNEL: 0 default, 1 "csr" (generic kernel), 2 "v2" (flip2_kernel)
+    uint32_t flip_maxflips = 0xFFFFFFFFu;   // LDPC_HIP_FLIP_MAXFLIPS (flip2 profiling aid)
+    int flip_lanes = 16;              // LDPC_HIP_FLIP_LANES (flip2: 16 or 8 lanes per shot)
+    bool flip_prof = false;           // LDPC_HIP_FLIP_PROF: flip3 reports cycles per phase in spare counters
+    int flip_bpc = 0;                 // LDPC_HIP_FLIP_BPC: flip3 blocks per CU (0: as many as LDS holds)
+    int bp_waves = 0;                 // LDPC_HIP_BP_WAVES (0: by code size)
+    int bp_oversub = 1;               // LDPC_HIP_BP_OVERSUB
+    int bp_path = 0;                  // LDPC_HIP_BP_PATH: 0 by size, 1 "stream", 2 "persistent"
+    long long bp_groups = 0;          // LDPC_HIP_BP_GROUPS (0: unset)
+    bool bp_handoff_set = false;      // LDPC_HIP_BP_HANDOFF given
+    uint32_t bp_handoff = 16;
+    bool bp_profile = false;          // LDPC_HIP_BP_PROFILE
+    bool bp_stream_skew = false;      // LDPC_HIP_BP_STREAM_SKEW
+    int bp_tail_burst = 0;            // LDPC_HIP_BP_TAIL_BURST (0: unset)
+    bool bp_no_compact = false;       // LDPC_HIP_BP_NO_COMPACT
+    int css_side_by_side = -1;        // LDPC_HIP_CSS_SIDE_BY_SIDE (-1: by size)
+    bool debug = false;               // LDPC_HIP_DEBUG
+};
+const Switches &switches();
+void reload_switches();
+
 enum NoiseSource : int {
     SRC_BSC = 0,          // sample BSC(p) on device
     SRC_DEPOL_X = 1,      // sample depolarizing(p), keep the x part (X or Y)
@@ -36,7 +61,8 @@ struct FlipArgs {
     uint64_t *o_scratch;        // fast kernel: [flip2_max_blocks][shots per wave][Wn] parked input words when errors_out is null
     uint32_t *flip_log;         // fast kernel: [flip2_max_blocks][shots per wave][flip_log_cap] flipped bits
     uint32_t flip_log_cap;      // >= m rounded up to 16, + 16
-    uint32_t list_cap;          // fast kernel: entries of the LDS error list (flip2_list_cap)
+    uint32_t list_cap;          // fast kernels: entries of the LDS error list (flip2_list_cap / flip3_list_cap)
+    double expected_weight;     // host only: mean weight of the channel's errors (sizes the list)
     GapTable gap;
 };
 
@@ -99,7 +125,22 @@ struct NbTable {
     uint32_t regular;      // every bit has exactly dvp checks (no sentinels among a valid slot's checks)
 };
 
+// Neighbourhood table of the third flip form (flip3_kernel): regular codes of bit degree 3, at most 16 slots per
+// row, at most 32 windows of 512 mask bits.  Row b = 16 records {bitp, chk0, chk1, chk2}; bitp = (byte offset of the
+// bit's 32-bit mask word) << 16 | bit in that word, chk as in NbTable.  Padding slots and the extra row n name the
+// spare mask bit (last bit of the last window) and the spare check m, which is never set.
+struct Nb3Table {
+    const uint4 *rec;      // [n + 1][16]
+    uint32_t sw;           // u64 words of a shot's syndrome in LDS: (m + 64) / 64
+    uint32_t windows;      // (n + 512) / 512, <= 32
+};
+
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g);
+size_t flip3_lds_bytes(const Nb3Table &t, uint32_t list_cap);
+uint32_t flip3_list_cap(double expected_weight);
+uint32_t flip3_max_blocks();
+uint32_t device_cu_count();
+hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st);
 size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot, uint32_t list_cap);
 uint32_t flip2_list_cap(double expected_weight);
 uint32_t flip2_lanes_per_shot(const DeviceGraph &g);

@@ -10,8 +10,10 @@ import ldpc_amd as L
 def run(dec, p, shots, path):
     if path:
         os.environ["LDPC_HIP_BP_PATH"] = path
+        L.reload_switches()
     else:
         os.environ.pop("LDPC_HIP_BP_PATH", None)
+        L.reload_switches()
     dec.mc_run(p, 2024, 0, shots)
     reps = 5 if shots <= 64 * 64 else 2
     t0 = time.perf_counter()

@@ -1,6 +1,7 @@
 """One-off parity stress of the BP kernels against the oracle on assorted codes (diagnostics)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ldpc_amd
 import numpy as np
 from ldpc_amd import BpDecoder, LinearCode, nwords
 from oracle import oracle as orc
@@ -19,6 +20,7 @@ for name, code in cases:
     oc = oracle_code(code)
     for path in ("persistent", "stream"):
         os.environ["LDPC_HIP_BP_PATH"] = path
+        ldpc_amd.reload_switches()
         for p, cap in ((0.01, 40), (0.06, 15)):
             shots = int(sys.argv[1]) if len(sys.argv) > 1 else 96
             syn = np.zeros((shots, max(nwords(m), 1)), dtype=np.uint64)

@@ -1,6 +1,7 @@
 """One-off parity stress of the flip kernels against the oracle on assorted codes (diagnostics)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ldpc_amd
 import numpy as np
 from ldpc_amd import FlipDecoder, LinearCode, nwords
 from oracle import oracle as orc
@@ -21,6 +22,7 @@ for name, code in cases:
     oc = oracle_code(code)
     for lanes in ("16", "8"):
         os.environ["LDPC_HIP_FLIP_LANES"] = lanes
+        ldpc_amd.reload_switches()
         dec = FlipDecoder(code)
         for p in (0.004, 0.03, 0.3):
             shots = 64
