@@ -407,20 +407,36 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         }
     }
     if (dec->path == 2 || dec->path == 3) {
-        const size_t max_blocks = dec->path == 3 ? flip3_max_blocks() : flip2_max_blocks(g);
+        if (dec->path == 3) a.list_cap = a.list_cap ? flip3_list_cap(a.expected_weight) : 512;   // given words: weight unknown
+        else if (!a.list_cap) a.list_cap = 512;
+        // large runs of the third form take the fourth (one workgroup per CU, flip waves fed by service waves);
+        // small ones would leave most of its slots empty
+        const bool v4 = dec->path == 3 && switches().flip_kernel != 3 && !switches().flip_prof &&
+                        a.n_shots >= (uint64_t)device_cu_count() * 256 && flip4_slots(dec->nbt3, a.list_cap, 8) >= 65;
+        // HBM scratch pieces: one parked word and one flip log per shot in flight
+        const size_t pieces = v4 ? flip4_scratch_pieces() : (size_t)(dec->path == 3 ? flip3_max_blocks() : flip2_max_blocks(g)) * 8;
         if (!a.errors_out) {
-            HIP_TRY(dec->o_scratch.reserve(max_blocks * 8 * std::max<size_t>(words_for(g.n), 1) * 8));
+            HIP_TRY(dec->o_scratch.reserve(pieces * std::max<size_t>(words_for(g.n), 1) * 8));
             a.o_scratch = dec->o_scratch.as<uint64_t>();
         }
         a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
-        if (dec->path == 3) a.list_cap = a.list_cap ? flip3_list_cap(a.expected_weight) : 512;   // given words: weight unknown
-        else if (!a.list_cap) a.list_cap = 512;
-        HIP_TRY(dec->flip_log.reserve(max_blocks * 8 * a.flip_log_cap * 4));
+        HIP_TRY(dec->flip_log.reserve(pieces * a.flip_log_cap * 4));
         a.flip_log = dec->flip_log.as<uint32_t>();
         KernelTimer timer;
-        if (dec->path == 3) HIP_TRY(launch_flip3(g, dec->nbt3, a, switches().flip_prof, g_stream));
+        if (v4) HIP_TRY(launch_flip4(g, dec->nbt3, a, g_stream));
+        else if (dec->path == 3) HIP_TRY(launch_flip3(g, dec->nbt3, a, switches().flip_prof, g_stream));
         else HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream));
         timer.stop_and_store();
+        if (v4) {
+            // the kernel's waves give up rather than wait for ever (a bug, not a run-time condition): never report
+            // counters of a run that did not finish
+            uint64_t c[LDPC_COUNTERS];
+            int rc = read_counters(dec->counters, c);
+            if (rc) return rc;
+            if (c[LDPC_CNT_SHOTS] != a.n_shots) return fail(LDPC_ERR_HIP, "flip decoder: the kernel stopped early (watchdog)");
+            if (counters_out) std::memcpy(counters_out, c, sizeof(c));
+            return LDPC_OK;
+        }
         if (counters_out) return read_counters(dec->counters, counters_out);
         HIP_TRY(hipStreamSynchronize(g_stream));
         return LDPC_OK;

@@ -741,12 +741,208 @@ __device__ inline bool rec3_flippable(const uint4 &r, const char *S)
 
 __host__ __device__ constexpr uint32_t flip3_hdr_words(uint32_t list_cap) { return 33 + list_cap / 4 + 1; }
 
+// Set-up of one shot, by one whole wave: noise (or the caller's word), syndrome and flippable mask into the shot's
+// LDS state S (Sw words, zeroed here together with the mask), F = S + Sw; the input word is parked at O (HBM) for the
+// output stage.  `list` (LIST_CAP u16) and `cnt_lds` are this wave's own LDS.  Returns the summary of F (bit w =
+// window w holds a flippable bit), the same value in every lane.  i = the shot's index within the call.
+__device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table &nbt, const FlipArgs &a, const uint32_t *q,
+                                            uint16_t *list, uint32_t LIST_CAP, uint32_t *cnt_lds, uint64_t *S, uint64_t *O,
+                                            uint64_t i, uint32_t lane)
+{
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    const uint32_t Sw = nbt.sw, per_shot = Sw + nbt.windows * 8;
+    const uint4 *nb = nbt.rec;
+    const uint32_t dummy_row = g.n;
+    uint64_t *F = S + Sw;
+    char *Sc = (char *)S, *Fc = (char *)F;
+    const uint64_t shot = a.first_shot + i;
+    uint32_t summary = 0;
+    for (uint32_t w = lane; w < per_shot; w += 64) S[w] = 0;
+    if (lane == 0) *cnt_lds = 0;
+    wave_order();
+    // noise (or the caller's word); error positions go to the LDS list as they appear
+    for (uint32_t w = lane; w < Wn; w += 64) {
+        const uint32_t nb_bits = bits_in_word(g.n, w);
+        uint64_t x;
+        if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
+        else {
+            x = a.words_in[i * Wn + w];
+            if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
+        }
+        O[w] = x;
+        const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+        if (cc) {
+            uint32_t off = atomicAdd(cnt_lds, cc);
+            while (x) {
+                if (off < LIST_CAP) list[off] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
+                off++;
+                x &= x - 1;
+            }
+        }
+    }
+    wave_sync();   // O is read back from memory below (overflow path) and by the output stage
+    const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
+    if (total <= LIST_CAP) {
+        // pass 1, syndrome: toggle the three checks of every error bit (slot 0 of its row)
+        for (uint32_t t0i = lane; t0i < total; t0i += 64 * 4) {
+            uint4 r[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (t0i + 64 * u < total) r[u] = nb[(size_t)list[t0i + 64 * u] << 4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (t0i + 64 * u < total) {
+                    atomicXor((uint32_t *)(Sc + (r[u].y >> 16)), 1u << (r[u].y & 31));
+                    atomicXor((uint32_t *)(Sc + (r[u].z >> 16)), 1u << (r[u].z & 31));
+                    atomicXor((uint32_t *)(Sc + (r[u].w >> 16)), 1u << (r[u].w & 31));
+                }
+        }
+        wave_order();
+        // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
+        // slot reads the spare check and is never flippable
+        constexpr uint32_t P2 = 8;
+        const uint32_t slots = total << 4;
+        for (uint32_t t0i = lane; t0i < slots; t0i += 64 * P2) {
+            uint4 r[P2];
+#pragma unroll
+            for (uint32_t u = 0; u < P2; u++) {
+                const uint32_t t = t0i + 64 * u;
+                r[u] = nb[((size_t)(t < slots ? list[t >> 4] : dummy_row) << 4) + (t & 15)];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < P2; u++)
+                if (rec3_flippable(r[u], Sc)) {
+                    atomicOr((uint32_t *)(Fc + (r[u].x >> 16)), 1u << (r[u].x & 31));
+                    summary |= 1u << (r[u].x >> 22);
+                }
+        }
+    } else {
+        // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words
+        const uint32_t pw = LIST_CAP / 64;
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t wb = 0; wb < Wn; wb += pw) {
+                wave_order();
+                if (lane == 0) *cnt_lds = 0;
+                wave_order();
+                const uint32_t w = wb + lane;
+                uint64_t x = (lane < pw && w < Wn) ? O[w] : 0;
+                const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+                if (cc) {
+                    uint32_t off = atomicAdd(cnt_lds, cc);
+                    while (x) {
+                        list[off++] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
+                        x &= x - 1;
+                    }
+                }
+                wave_order();
+                const uint32_t cnt = __builtin_amdgcn_readfirstlane(*cnt_lds);
+                if (pass == 0) {
+                    for (uint32_t t = lane; t < cnt; t += 64) {
+                        const uint4 r = nb[(size_t)list[t] << 4];
+                        atomicXor((uint32_t *)(Sc + (r.y >> 16)), 1u << (r.y & 31));
+                        atomicXor((uint32_t *)(Sc + (r.z >> 16)), 1u << (r.z & 31));
+                        atomicXor((uint32_t *)(Sc + (r.w >> 16)), 1u << (r.w & 31));
+                    }
+                } else {
+                    for (uint32_t t = lane; t < (cnt << 4); t += 64) {
+                        const uint4 r = nb[((size_t)list[t >> 4] << 4) + (t & 15)];
+                        if (rec3_flippable(r, Sc)) {
+                            atomicOr((uint32_t *)(Fc + (r.x >> 16)), 1u << (r.x & 31));
+                            summary |= 1u << (r.x >> 22);
+                        }
+                    }
+                }
+            }
+            wave_order();
+        }
+    }
+    wave_order();
+    if (a.synd_out)
+        for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+    return (uint32_t)wave_or64(summary);
+}
+
+// Output of one finished shot, by one whole wave: the decoded word = parked input word (E, HBM) with the nf logged
+// flips (lj, HBM) applied (flip.rs:30, deferred), rebuilt in the shot's dead F region; failure test against the
+// all-zero codeword.  Returns bit 0 = decoded word non-zero (failure), bit 1 = final syndrome non-zero (detected).
+__device__ inline uint32_t flip3_output_shot(const DeviceGraph &g, const Nb3Table &nbt, const FlipArgs &a, uint64_t *S,
+                                             const uint64_t *E, const uint16_t *lj, uint32_t nf, uint64_t i, uint32_t lane)
+{
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    uint64_t *Oj = S + nbt.sw;
+    uint32_t *O32 = (uint32_t *)Oj;
+    // device-scope loads: both were written through other lanes / waves of this CU
+    for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&E[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wave_order();
+    for (uint32_t t0i = lane; t0i < nf; t0i += 64 * 4) {
+        uint32_t bb[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            bb[u] = t0i + 64 * u < nf ? (uint32_t)__hip_atomic_load(&lj[t0i + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (bb[u] != NONE) atomicXor(&O32[bb[u] >> 5], 1u << (bb[u] & 31));                // flip.rs:30
+    }
+    wave_order();
+    uint64_t anyo = 0, anys = 0;
+    for (uint32_t w = lane; w < Wn; w += 64) {
+        const uint64_t x = Oj[w];
+        anyo |= x;
+        if (a.words_out) a.words_out[i * Wn + w] = x;
+    }
+    for (uint32_t w = lane; w < Wm; w += 64) anys |= S[w];
+    const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
+    if (a.flips_out && lane == 0) a.flips_out[i] = nf;
+    return (fail ? 1u : 0u) | (det ? 2u : 0u);
+}
+
+// One iteration of the serial flip loop for the eight shots of a wave (8 lanes each): the lowest flippable bit of
+// each shot is flipped (flip.rs:27-30), or, when the scanned window of its mask holds none, the window is retired.
+// Sg / Fg: the group's shot state in LDS; fs2: summary of F (0: nothing to do -- the group then works the spare row
+// and changes nothing); nfl: flips so far = position in the flip log.
+__device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg, char *Fg, uint16_t *flog, uint32_t gl,
+                                  uint32_t &fs2, uint32_t &nfl)
+{
+    const uint32_t Fg_addr = lds_addr_of(Fg);
+    const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
+    const uint64_t x = *(const uint64_t *)(Fg + (w2 << 6) + gl * 8);
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    // lowest set bit of the lane's 64 mask bits; all ones when there is none
+    const uint32_t clo = lo ? (uint32_t)__builtin_ctz(lo) : NONE, chi = hi ? (uint32_t)__builtin_ctz(hi) | 32u : NONE;
+    const uint32_t c = (clo < chi ? clo : chi) | (gl << 6);
+    const uint32_t mpos = half_row_min2_u32(c);
+    const bool found = fs2 != 0 && mpos != NONE;
+    // the window is empty, or the bit about to be flipped is its only one: retire it (a neighbour that
+    // becomes flippable in it sets the summary bit again below)
+    const uint32_t inwin = half_row_add_u32((uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi));
+    if (inwin <= 1) fs2 &= fs2 - 1;
+    const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
+    const uint4 r0 = nbl[(size_t)b << 4], r1 = nbl[((size_t)b << 4) + 1];
+    const uint32_t one = found ? 1u : 0u;
+    if (gl == 0) {                                             // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
+        atomicXor((uint32_t *)(Sg + (r0.y >> 16)), one << (r0.y & 31));
+        atomicXor((uint32_t *)(Sg + (r0.z >> 16)), one << (r0.z & 31));
+        atomicXor((uint32_t *)(Sg + (r0.w >> 16)), one << (r0.w & 31));
+        flog[nfl] = (uint16_t)b;                               // output ^= e_b (flip.rs:30) is deferred: log the flip
+    }
+    wave_order();
+    // both slots re-evaluate their bit against the new syndrome and rewrite its F bit
+    const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
+    const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
+    lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
+    lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
+    const uint32_t contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
+    fs2 |= half_row_or_u32(contrib);
+    nfl += one;
+    wave_order();
+}
+
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
     constexpr uint32_t SPW = 8;                      // shots per wave, 8 lanes each
     const uint32_t lane = threadIdx.x, grp = lane >> 3, gl = lane & 7;
-    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    const uint32_t Wn = (g.n + 63) / 64;
     const uint32_t Sw = nbt.sw, windows = nbt.windows, Fw = windows * 8;
     const uint32_t per_shot = Sw + Fw;               // LDS words per shot: S (with the spare check), F in whole windows
     uint32_t *q = (uint32_t *)lds;
@@ -754,8 +950,6 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
     const uint32_t LIST_CAP = a.list_cap;
     uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 4);
     uint64_t *state = lds + flip3_hdr_words(LIST_CAP);
-    const uint4 *nb = nbt.rec;
-    const uint32_t dummy_row = g.n;
 
     for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
     wave_sync();
@@ -767,109 +961,17 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
         const uint32_t nvalid = a.n_shots - base < SPW ? (uint32_t)(a.n_shots - base) : SPW;
         unsigned long long t0 = 0;
         if (PROF) t0 = __builtin_amdgcn_s_memtime();
+        // the sampled / given word of shot j is parked in HBM during the flip loop (the caller's record
+        // buffer, or this block's scratch slice); the flips are logged and applied to it at the end
         auto err_words = [&](uint32_t j) -> uint64_t * {
             return a.errors_out ? a.errors_out + (base + j) * Wn : a.o_scratch + ((size_t)blockIdx.x * SPW + j) * Wn;
         };
         // ------------------------------------------------------------------ set-up, wave-wide, shot by shot
+        uint32_t fs2 = 0;
         for (uint32_t j = 0; j < nvalid; j++) {
-            uint64_t *S = state + (size_t)j * per_shot, *F = S + Sw, *O = err_words(j);
-            char *Sc = (char *)S, *Fc = (char *)F;
-            const uint64_t i = base + j, shot = a.first_shot + i;
-            for (uint32_t w = lane; w < per_shot; w += 64) S[w] = 0;
-            if (lane == 0) *cnt_lds = 0;
-            wave_order();
-            for (uint32_t w = lane; w < Wn; w += 64) {
-                const uint32_t nb_bits = bits_in_word(g.n, w);
-                uint64_t x;
-                if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
-                else {
-                    x = a.words_in[i * Wn + w];
-                    if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
-                }
-                O[w] = x;
-                const uint32_t cc = (uint32_t)__builtin_popcountll(x);
-                if (cc) {
-                    uint32_t off = atomicAdd(cnt_lds, cc);
-                    while (x) {
-                        if (off < LIST_CAP) list[off] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
-                        off++;
-                        x &= x - 1;
-                    }
-                }
-            }
-            wave_sync();   // O is read back from memory below (overflow path) and at the end
-            const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
-            if (total <= LIST_CAP) {
-                // pass 1, syndrome: toggle the three checks of every error bit (slot 0 of its row)
-                for (uint32_t t0i = lane; t0i < total; t0i += 64 * 4) {
-                    uint4 r[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
-                        if (t0i + 64 * u < total) r[u] = nb[(size_t)list[t0i + 64 * u] << 4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++)
-                        if (t0i + 64 * u < total) {
-                            atomicXor((uint32_t *)(Sc + (r[u].y >> 16)), 1u << (r[u].y & 31));
-                            atomicXor((uint32_t *)(Sc + (r[u].z >> 16)), 1u << (r[u].z & 31));
-                            atomicXor((uint32_t *)(Sc + (r[u].w >> 16)), 1u << (r[u].w & 31));
-                        }
-                }
-                wave_order();
-                // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
-                // slot reads the spare check and is never flippable
-                constexpr uint32_t P2 = 8;
-                const uint32_t slots = total << 4;
-                for (uint32_t t0i = lane; t0i < slots; t0i += 64 * P2) {
-                    uint4 r[P2];
-#pragma unroll
-                    for (uint32_t u = 0; u < P2; u++) {
-                        const uint32_t t = t0i + 64 * u;
-                        r[u] = nb[((size_t)(t < slots ? list[t >> 4] : dummy_row) << 4) + (t & 15)];
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < P2; u++)
-                        if (rec3_flippable(r[u], Sc)) atomicOr((uint32_t *)(Fc + (r[u].x >> 16)), 1u << (r[u].x & 31));
-                }
-            } else {
-                // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words
-                const uint32_t pw = LIST_CAP / 64;
-                for (int pass = 0; pass < 2; pass++) {
-                    for (uint32_t wb = 0; wb < Wn; wb += pw) {
-                        wave_order();
-                        if (lane == 0) *cnt_lds = 0;
-                        wave_order();
-                        const uint32_t w = wb + lane;
-                        uint64_t x = (lane < pw && w < Wn) ? O[w] : 0;
-                        const uint32_t cc = (uint32_t)__builtin_popcountll(x);
-                        if (cc) {
-                            uint32_t off = atomicAdd(cnt_lds, cc);
-                            while (x) {
-                                list[off++] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
-                                x &= x - 1;
-                            }
-                        }
-                        wave_order();
-                        const uint32_t cnt = __builtin_amdgcn_readfirstlane(*cnt_lds);
-                        if (pass == 0) {
-                            for (uint32_t t = lane; t < cnt; t += 64) {
-                                const uint4 r = nb[(size_t)list[t] << 4];
-                                atomicXor((uint32_t *)(Sc + (r.y >> 16)), 1u << (r.y & 31));
-                                atomicXor((uint32_t *)(Sc + (r.z >> 16)), 1u << (r.z & 31));
-                                atomicXor((uint32_t *)(Sc + (r.w >> 16)), 1u << (r.w & 31));
-                            }
-                        } else {
-                            for (uint32_t t = lane; t < (cnt << 4); t += 64) {
-                                const uint4 r = nb[((size_t)list[t >> 4] << 4) + (t & 15)];
-                                if (rec3_flippable(r, Sc)) atomicOr((uint32_t *)(Fc + (r.x >> 16)), 1u << (r.x & 31));
-                            }
-                        }
-                    }
-                    wave_order();
-                }
-            }
-            wave_order();
-            if (a.synd_out)
-                for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+            const uint32_t s = flip3_setup_shot(g, nbt, a, q, list, LIST_CAP, cnt_lds, state + (size_t)j * per_shot, err_words(j),
+                                                base + j, lane);
+            if (grp == j) fs2 = s;
         }
         unsigned long long t1 = 0;
         if (PROF) t1 = __builtin_amdgcn_s_memtime();
@@ -877,52 +979,13 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
         uint32_t nfl = 0;
         {
             char *Sg = (char *)(state + (size_t)grp * per_shot), *Fg = Sg + (size_t)Sw * 8;
-            const uint32_t Fg_addr = lds_addr_of(Fg);
-            uint32_t *flog = a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;
-            const uint4 *nbl = nb + gl * 2;            // the lane's two slots of a row
-            // summary of F: bit w = window w holds a flippable bit
-            uint32_t fs2 = 0;
-            for (uint32_t w = 0; w < windows; w++) {
-                const uint64_t x = *(const uint64_t *)(Fg + (w << 6) + gl * 8);
-                fs2 |= (x != 0 ? 1u : 0u) << w;
-            }
-            fs2 = half_row_or_u32(fs2);
-            if (grp >= nvalid) fs2 = 0;
+            uint16_t *flog = (uint16_t *)a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;   // n < 2^16
+            const uint4 *nbl = nbt.rec + gl * 2;       // the lane's two slots of a row
             // every iteration flips a bit (at most m flips: each lowers the syndrome weight) or retires a window
-            const uint32_t iter_cap = g.m + 33 * (g.m + 2) + 64;
+            const uint32_t iter_cap = 18 * g.m + 64;
             for (uint32_t it = 0; it < iter_cap; it++) {
                 if (!__ballot(fs2 != 0)) break;                            // flip.rs:27 find_flippable == None, all shots
-                const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
-                const uint64_t x = *(const uint64_t *)(Fg + (w2 << 6) + gl * 8);
-                const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-                // lowest set bit of the lane's 64 mask bits; all ones when there is none
-                const uint32_t clo = lo ? (uint32_t)__builtin_ctz(lo) : NONE, chi = hi ? (uint32_t)__builtin_ctz(hi) | 32u : NONE;
-                const uint32_t c = (clo < chi ? clo : chi) | (gl << 6);
-                const uint32_t mpos = half_row_min2_u32(c);
-                const bool found = fs2 != 0 && mpos != NONE;
-                // the window is empty, or the bit about to be flipped is its only one: retire it (a neighbour that
-                // becomes flippable in it sets the summary bit again below)
-                const uint32_t inwin = half_row_add_u32((uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi));
-                if (inwin <= 1) fs2 &= fs2 - 1;
-                const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
-                const uint4 r0 = nbl[(size_t)b << 4], r1 = nbl[((size_t)b << 4) + 1];
-                const uint32_t one = found ? 1u : 0u;
-                if (gl == 0) {                                             // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
-                    atomicXor((uint32_t *)(Sg + (r0.y >> 16)), one << (r0.y & 31));
-                    atomicXor((uint32_t *)(Sg + (r0.z >> 16)), one << (r0.z & 31));
-                    atomicXor((uint32_t *)(Sg + (r0.w >> 16)), one << (r0.w & 31));
-                    flog[nfl] = b;                                         // output ^= e_b (flip.rs:30) is deferred: log the flip
-                }
-                wave_order();
-                // both slots re-evaluate their bit against the new syndrome and rewrite its F bit
-                const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
-                const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
-                lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
-                lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
-                const uint32_t contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
-                fs2 |= half_row_or_u32(contrib);
-                nfl += one;
-                wave_order();
+                flip3_step(nbl, g.n, Sg, Fg, flog, gl, fs2, nfl);
                 if (PROF) n_iter++;
             }
         }
@@ -931,34 +994,11 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
         if (PROF) t2 = __builtin_amdgcn_s_memtime();
         // ---------------------------------------------------------------- failure test + outputs
         for (uint32_t j = 0; j < nvalid; j++) {
-            uint64_t *Sj = state + (size_t)j * per_shot, *Oj = Sj + Sw;   // F is dead: rebuild the word there
-            uint32_t *O32 = (uint32_t *)Oj;
-            const uint64_t *Ej = err_words(j);
-            const uint32_t *lj = a.flip_log + ((size_t)blockIdx.x * SPW + j) * a.flip_log_cap;
-            const uint64_t i = base + j;
             const uint32_t nfj = __shfl(nfl, j * 8, 64), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
-            for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&Ej[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wave_order();
-            for (uint32_t t0i = lane; t0i < nf; t0i += 64 * 4) {
-                uint32_t bb[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
-                    bb[u] = t0i + 64 * u < nf ? __hip_atomic_load(&lj[t0i + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
-                    if (bb[u] != NONE) atomicXor(&O32[bb[u] >> 5], 1u << (bb[u] & 31));                // flip.rs:30
-            }
-            wave_order();
-            uint64_t anyo = 0, anys = 0;
-            for (uint32_t w = lane; w < Wn; w += 64) {
-                const uint64_t x = Oj[w];
-                anyo |= x;
-                if (a.words_out) a.words_out[i * Wn + w] = x;
-            }
-            for (uint32_t w = lane; w < Wm; w += 64) anys |= Sj[w];
-            const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
-            if (a.flips_out && lane == 0) a.flips_out[i] = nf;
-            c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nf;
+            const uint32_t r = flip3_output_shot(g, nbt, a, state + (size_t)j * per_shot, err_words(j),
+                                                 (const uint16_t *)a.flip_log + ((size_t)blockIdx.x * SPW + j) * a.flip_log_cap, nf,
+                                                 base + j, lane);
+            c_shots++; c_fail += r & 1; c_det += (r >> 1) & 1; c_undet += r == 1; c_flips += nf;
         }
         wave_sync();
         if (PROF) {
@@ -979,6 +1019,244 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// Flip decoder, fourth form = the third with the work of a shot split over two
+// kinds of waves of one 1024-thread workgroup per CU (large runs):
+//   * NF flip waves run flip3_step and nothing else: eight shots each, and a
+//     group of 8 lanes whose shot has finished hands it back and takes the next
+//     prepared one, so all eight chains of a wave stay busy (no waiting for the
+//     slowest of eight, no set-up in front of the loop);
+//   * 16 - NF service waves prepare shots (noise, syndrome, flippable mask:
+//     flip3_setup_shot) into free LDS slots and turn finished ones into outputs
+//     (flip3_output_shot).
+// A slot = one shot's state in LDS; its status word walks FREE -> (service
+// wave) SETUP -> READY -> (flip group) RUNNING -> DONE -> (service wave) ... .
+// All hand-offs are inside one workgroup: LDS status words written after a
+// workgroup-scope release, taken with LDS compare-and-swap.
+// ---------------------------------------------------------------------------
+constexpr uint32_t F4_FREE = 0, F4_HELD = 1, F4_READY = 2, F4_RUNNING = 3, F4_DONE = 4;
+constexpr uint32_t F4_MAX_SLOTS = 128;
+constexpr uint32_t F4_LOGS = F4_MAX_SLOTS + 16;   // flip logs / parked words per block in HBM scratch
+
+struct Flip4Ctl {
+    uint32_t status[F4_MAX_SLOTS];
+    uint32_t shot[F4_MAX_SLOTS];     // index of the slot's shot within this block's range
+    uint32_t nfl[F4_MAX_SLOTS];      // flips logged (written by the flip group on DONE)
+    uint32_t fs2[F4_MAX_SLOTS];      // summary of F (written by the service wave on READY)
+    uint32_t next_shot;              // shots handed to service waves so far
+    uint32_t n_flipped;              // shots whose flip loop has ended
+    uint32_t n_output;               // shots written out
+    uint32_t abort;                  // watchdog: a wave gave up waiting (never in a correct run)
+    uint32_t cnt[16];                // per service wave: list fill counter
+};
+
+__host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32_t helpers)
+{
+    return 34 + (uint32_t)(sizeof(Flip4Ctl) / 8) + helpers * (list_cap / 4);
+}
+
+template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
+{
+    extern __shared__ uint64_t lds[];
+    constexpr uint32_t NH = 16 - NF;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t grp = lane >> 3, gl = lane & 7;
+    const uint32_t Wn = (g.n + 63) / 64;
+    const uint32_t Sw = nbt.sw, per_shot = Sw + nbt.windows * 8;
+    const uint32_t LIST_CAP = a.list_cap;
+    uint32_t *q = (uint32_t *)lds;
+    Flip4Ctl *ctl = (Flip4Ctl *)(lds + 34);
+    uint16_t *lists = (uint16_t *)(lds + 34 + sizeof(Flip4Ctl) / 8);
+    uint64_t *state = lds + flip4_hdr_words(LIST_CAP, NH);
+    // this block's contiguous range of the call's shots
+    const uint64_t chunk = (a.n_shots + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    const uint32_t count = lo >= a.n_shots ? 0u : (uint32_t)(a.n_shots - lo < chunk ? a.n_shots - lo : chunk);
+    if (count == 0) return;
+
+    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = a.gap.q[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(Flip4Ctl) / 4; i += blockDim.x) ((uint32_t *)ctl)[i] = 0;
+    __syncthreads();
+
+    // scratch in HBM, one piece per (block, slot): parked input word (unless the caller records errors), flip log
+    auto err_words = [&](uint32_t slot, uint32_t rel) -> uint64_t * {
+        return a.errors_out ? a.errors_out + (lo + rel) * Wn : a.o_scratch + ((size_t)blockIdx.x * F4_LOGS + slot) * Wn;
+    };
+    // (logs F4_MAX_SLOTS + w: waste bin of flip wave w, for the no-op rounds of groups without a shot)
+    auto log_of = [&](uint32_t slot) -> uint16_t * {
+        return (uint16_t *)a.flip_log + ((size_t)blockIdx.x * F4_LOGS + slot) * a.flip_log_cap;
+    };
+    // first slot with status `want` among slots [0, n_slots), or NONE (wave-uniform)
+    auto find_slot = [&](uint32_t want) -> uint32_t {
+        const uint64_t m0 = __ballot(lane < n_slots && __hip_atomic_load(&ctl->status[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want);
+        if (m0) return (uint32_t)__builtin_ctzll(m0);
+        const uint64_t m1 = __ballot(lane + 64 < n_slots && __hip_atomic_load(&ctl->status[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want);
+        return m1 ? 64u + (uint32_t)__builtin_ctzll(m1) : NONE;
+    };
+    constexpr uint32_t IDLE_CAP = 1u << 22;   // polls without progress before a wave gives up (~ seconds)
+
+    if (wave >= NF) {
+        // ================================================================= service wave
+        const uint32_t h = wave - NF;
+        uint16_t *list = lists + (size_t)h * LIST_CAP;
+        uint32_t *cnt_lds = &ctl->cnt[h];
+        uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+        uint32_t idle = 0;
+        for (;;) {
+            if (__hip_atomic_load(&ctl->n_output, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= count) break;
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            // a finished shot first (its slot is then reused), else a free slot while shots remain
+            uint32_t slot = find_slot(F4_DONE), from = F4_DONE;
+            if (slot == NONE && __hip_atomic_load(&ctl->next_shot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < count) {
+                slot = find_slot(F4_FREE);
+                from = F4_FREE;
+            }
+            uint32_t got = 0;
+            if (slot != NONE) {
+                if (lane == 0) {
+                    uint32_t expect = from;
+                    got = __hip_atomic_compare_exchange_strong(&ctl->status[slot], &expect, F4_HELD, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+            }
+            if (!got) {
+                if (++idle > IDLE_CAP) {
+                    if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            idle = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint64_t *S = state + (size_t)slot * per_shot;
+            if (from == F4_DONE) {
+                const uint32_t rel = __builtin_amdgcn_readfirstlane(ctl->shot[slot]);
+                const uint32_t nfj = __builtin_amdgcn_readfirstlane(ctl->nfl[slot]), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
+                const uint32_t r = flip3_output_shot(g, nbt, a, S, err_words(slot, rel), log_of(slot), nf, lo + rel, lane);
+                c_shots++; c_fail += r & 1; c_det += (r >> 1) & 1; c_undet += r == 1; c_flips += nf;
+                wave_sync();
+                if (lane == 0) __hip_atomic_fetch_add(&ctl->n_output, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // the next shot of the block goes into the slot, if there is one
+            uint32_t rel = 0;
+            if (lane == 0) rel = __hip_atomic_fetch_add(&ctl->next_shot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rel = __builtin_amdgcn_readfirstlane(rel);
+            if (rel >= count) {
+                // (next_shot may run past count by the number of service waves; the slot is retired)
+                if (lane == 0) __hip_atomic_store(&ctl->status[slot], F4_HELD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+            const uint32_t s = flip3_setup_shot(g, nbt, a, q, list, LIST_CAP, cnt_lds, S, err_words(slot, rel), lo + rel, lane);
+            if (lane == 0) {
+                ctl->shot[slot] = rel;
+                ctl->fs2[slot] = s;
+            }
+            wave_sync();   // state, parked word: written before the slot is offered
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&ctl->status[slot], F4_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (lane == 0 && a.counters) {
+            if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+            if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+            if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+            if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
+            if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+        }
+        return;
+    }
+    // ===================================================================== flip wave
+    if (a.max_flips == 1) __builtin_amdgcn_s_setprio(3);   // (experiment) the serial chains win the issue arbitration
+    const uint4 *nbl = nbt.rec + gl * 2;
+    uint32_t slot = NONE, fs2 = 0, nfl = 0, idle = 0, steps = 0;
+    char *Sg = (char *)state, *Fg = Sg + (size_t)Sw * 8;
+    uint16_t *const waste = log_of(F4_MAX_SLOTS + wave);
+    uint16_t *flog = waste;
+    const uint32_t step_cap = 18 * g.m + 64;   // flips (<= m, each lowers the syndrome weight) + window retirements of one shot
+    for (;;) {
+        if (__ballot(fs2 == 0)) {
+            // ---- some group has nothing to flip: hand finished shots back, take prepared ones
+            const bool finished = fs2 == 0 && slot != NONE;
+            if (__ballot(finished)) {
+                wave_sync();   // this wave's log entries are in memory
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (finished && gl == 0) {
+                    ctl->nfl[slot] = nfl;
+                    __hip_atomic_store(&ctl->status[slot], F4_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&ctl->n_flipped, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (finished) {
+                    // the group's no-op rounds must not touch the slot's log (its next shot writes there)
+                    slot = NONE;
+                    flog = waste;
+                    nfl = 0;
+                }
+            }
+            // ready slots (two status words per lane), dealt to the groups that need one in lane order
+            const uint64_t r0 = __ballot(lane < n_slots && __hip_atomic_load(&ctl->status[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == F4_READY);
+            const uint64_t r1 = __ballot(lane + 64 < n_slots && __hip_atomic_load(&ctl->status[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == F4_READY);
+            const uint64_t needm = __ballot(slot == NONE && gl == 0);
+            bool took = false;
+            if (r0 | r1) {
+                // group k of the needy ones (in lane order) tries the k-th ready slot
+                const uint32_t rank = (uint32_t)__builtin_popcountll(needm & ((1ull << (grp * 8)) - 1));
+                uint32_t cand = NONE;
+                {
+                    uint64_t x0 = r0, x1 = r1;
+                    uint32_t k = rank;
+                    // k-th set bit of (r1:r0); at most 8 steps
+                    for (uint32_t s = 0; s < 8; s++) {
+                        if (s == k) cand = x0 ? (uint32_t)__builtin_ctzll(x0) : x1 ? 64u + (uint32_t)__builtin_ctzll(x1) : NONE;
+                        if (x0) x0 &= x0 - 1;
+                        else x1 &= x1 - 1;
+                    }
+                }
+                uint32_t ok = 0;
+                if (slot == NONE && cand != NONE && gl == 0) {
+                    uint32_t expect = F4_READY;
+                    ok = __hip_atomic_compare_exchange_strong(&ctl->status[cand], &expect, F4_RUNNING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                }
+                ok = __shfl(ok, grp * 8, 64);   // the group's lane 0 made the attempt
+                cand = __shfl(cand, grp * 8, 64);
+                if (slot == NONE && ok) {
+                    slot = cand;
+                    took = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (took) {
+                    fs2 = ctl->fs2[slot];
+                    nfl = 0;
+                    Sg = (char *)(state + (size_t)slot * per_shot);
+                    Fg = Sg + (size_t)Sw * 8;
+                    flog = log_of(slot);
+                    steps = 0;
+                    // (a shot with nothing to flip has fs2 == 0 and is handed back on the next pass)
+                }
+            }
+            if (!__ballot(slot != NONE)) {
+                // every group is idle: done when the block's shots have all been flipped
+                if (__hip_atomic_load(&ctl->n_flipped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= count) break;
+                if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                if (++idle > IDLE_CAP) {
+                    if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            idle = 0;
+        }
+        flip3_step(nbl, g.n, Sg, Fg, flog, gl, fs2, nfl);
+        if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
+            if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------
 // Belief propagation.  One workgroup of NW waves owns a group of 64 shot slots;
@@ -2119,11 +2397,12 @@ std::once_flag g_switches_once;
 Switches read_switches()
 {
     Switches s;
-    if (const char *e = std::getenv("LDPC_HIP_FLIP_KERNEL")) s.flip_kernel = !std::strcmp(e, "csr") ? 1 : !std::strcmp(e, "v2") ? 2 : 0;
     if (const char *e = std::getenv("LDPC_HIP_FLIP_MAXFLIPS")) s.flip_maxflips = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char *e = std::getenv("LDPC_HIP_FLIP_LANES")) s.flip_lanes = std::atoi(e) == 8 ? 8 : 16;
     s.flip_prof = std::getenv("LDPC_HIP_FLIP_PROF") != nullptr;
     if (const char *e = std::getenv("LDPC_HIP_FLIP_BPC")) s.flip_bpc = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_NF")) s.flip_nf = std::atoi(e);
+    if (const char *e = std::getenv("LDPC_HIP_FLIP_KERNEL")) s.flip_kernel = !std::strcmp(e, "csr") ? 1 : !std::strcmp(e, "v2") ? 2 : !std::strcmp(e, "v3") ? 3 : 0;
     if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) s.bp_waves = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) s.bp_oversub = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) s.bp_path = !std::strcmp(e, "stream") ? 1 : !std::strcmp(e, "persistent") ? 2 : 0;
@@ -2200,6 +2479,42 @@ hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
     const uint32_t grid = grid_for(a.n_shots, 8, device_cu_count() * per_cu);
     if (prof) hipLaunchKernelGGL(flip3_kernel<true>, dim3(grid), dim3(64), lds, st, g, nb, a);
     else hipLaunchKernelGGL(flip3_kernel<false>, dim3(grid), dim3(64), lds, st, g, nb, a);
+    return hipGetLastError();
+}
+
+// flip4: slots that fit the CU's LDS beside the header (a little is left unused: the hardware's allocation granule)
+uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf)
+{
+    const size_t hdr = (size_t)flip4_hdr_words(list_cap, 16 - nf) * 8, per = ((size_t)t.sw + (size_t)t.windows * 8) * 8;
+    const size_t room = 160 * 1024 - 2048;
+    if (hdr + per > room) return 0;
+    return (uint32_t)std::min<size_t>(F4_MAX_SLOTS, (room - hdr) / per);
+}
+
+uint32_t flip4_scratch_pieces() { return device_cu_count() * F4_LOGS; }
+
+hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    uint32_t nf = 8;
+    if (switches().flip_nf >= 4 && switches().flip_nf <= 12) nf = (uint32_t)switches().flip_nf;
+    const uint32_t n_slots = flip4_slots(nb, a.list_cap, nf);
+    if (n_slots < nf * 8 + 1 || a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, 16 - nf) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(device_cu_count(), (a.n_shots + 63) / 64);
+    void (*k)(DeviceGraph, Nb3Table, FlipArgs, uint32_t) = flip4_kernel<8>;
+    switch (nf) {   // (A/B aid: LDPC_HIP_FLIP_NF)
+    case 4: k = flip4_kernel<4>; break;
+    case 6: k = flip4_kernel<6>; break;
+    case 7: k = flip4_kernel<7>; break;
+    case 9: k = flip4_kernel<9>; break;
+    case 10: k = flip4_kernel<10>; break;
+    default: nf = 8; break;
+    }
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (switches().debug) std::fprintf(stderr, "[ldpc_hip] flip4: %u flip waves, %u slots, lds %zu B, grid %u\n", nf, n_slots, lds, grid);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, g, nb, a, n_slots);
     return hipGetLastError();
 }
 

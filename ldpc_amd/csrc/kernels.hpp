@@ -13,11 +13,12 @@ namespace ldpc {
 // production).  The environment is read ONCE, when the library first needs a switch; a test that changes a variable
 // afterwards calls ldpc_debug_reload_switches() (not meant to run beside decoding calls of other threads).
 struct Switches {
-    int flip_kernel = 0;              // LDPC_HIP_FLIP_KERNEL: 0 default, 1 "csr" (generic kernel), 2 "v2" (flip2_kernel)
+    int flip_kernel = 0;              // LDPC_HIP_FLIP_KERNEL: 0 default, 1 "csr" (generic kernel), 2 "v2" (flip2_kernel), 3 "v3" (flip3_kernel also for large runs)
     uint32_t flip_maxflips = 0xFFFFFFFFu;   // LDPC_HIP_FLIP_MAXFLIPS (flip2 profiling aid)
     int flip_lanes = 16;              // LDPC_HIP_FLIP_LANES (flip2: 16 or 8 lanes per shot)
     bool flip_prof = false;           // LDPC_HIP_FLIP_PROF: flip3 reports cycles per phase in spare counters
     int flip_bpc = 0;                 // LDPC_HIP_FLIP_BPC: flip3 blocks per CU (0: as many as LDS holds)
+    int flip_nf = 0;                  // LDPC_HIP_FLIP_NF: flip4 flip waves of the 16 (0: default 8)
     int bp_waves = 0;                 // LDPC_HIP_BP_WAVES (0: by code size)
     int bp_oversub = 1;               // LDPC_HIP_BP_OVERSUB
     int bp_path = 0;                  // LDPC_HIP_BP_PATH: 0 by size, 1 "stream", 2 "persistent"
@@ -141,6 +142,10 @@ uint32_t flip3_list_cap(double expected_weight);
 uint32_t flip3_max_blocks();
 uint32_t device_cu_count();
 hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st);
+// fourth form (large runs): one 1024-thread workgroup per CU, flip waves + service waves
+uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf);
+uint32_t flip4_scratch_pieces();   // pieces (parked word / flip log) of HBM scratch a launch may index
+hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, hipStream_t st);
 size_t flip2_lds_bytes(const DeviceGraph &g, uint32_t lanes_per_shot, uint32_t list_cap);
 uint32_t flip2_list_cap(double expected_weight);
 uint32_t flip2_lanes_per_shot(const DeviceGraph &g);
