@@ -344,23 +344,39 @@ bool build_nb3_table(const LinearCode &c, std::vector<uint32_t> &out, Nb3Table &
         out[s * 4] = pack(spare_bit);
         out[s * 4 + 1] = out[s * 4 + 2] = out[s * 4 + 3] = pack(spare_chk);
     }
+    // Record of a slot: word 0 = mask position of the slot's bit | flags, words 1, 2 = the checks the flip loop reads
+    // from the syndrome, word 3 = the check that connects the slot's bit to the row's bit b (the loop takes its new
+    // value from the lane that toggled it).  Flags: bit 8 = "always rewrite the mask bit" (b itself, and a bit that
+    // shares more than one check with b: its old state cannot be told from one check), bits 9-10 = which of b's three
+    // checks word 3 is.  Slot 0 is b itself (word 3 = its third check).
     std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
     for (uint32_t b = 0; b < n; b++) {
         size_t slot = 0;
-        auto put = [&](uint32_t bit) {
+        auto put = [&](uint32_t bit, uint32_t conn_k, bool always) {
             uint32_t *r = &out[((size_t)b * 16 + slot++) * 4];
-            r[0] = pack(bit);
-            for (uint32_t k = 0; k < 3; k++) r[1 + k] = pack(t.idx[t.ptr[bit] + k]);
+            const uint32_t conn = t.idx[t.ptr[b] + conn_k];
+            r[0] = pack(bit) | (always ? 1u << 8 : 0u) | conn_k << 9;
+            uint32_t w = 1;
+            bool seen = false;
+            for (uint32_t k = 0; k < 3; k++) {
+                const uint32_t c = t.idx[t.ptr[bit] + k];
+                if (c == conn && !seen) seen = true;
+                else r[w++] = pack(c);
+            }
+            r[3] = pack(conn);
         };
         stamp[b] = b;
-        put(b);
+        put(b, 2, true);
         for (uint32_t k = t.ptr[b]; k < t.ptr[b + 1]; k++)
             for (uint32_t e = h.ptr[t.idx[k]]; e < h.ptr[t.idx[k] + 1]; e++) {
                 const uint32_t bb = h.idx[e];
                 if (stamp[bb] == b) continue;
                 if (slot == 16) return false;   // more than 15 neighbours
                 stamp[bb] = b;
-                put(bb);
+                uint32_t shared = 0;
+                for (uint32_t k2 = 0; k2 < 3; k2++)
+                    for (uint32_t k3 = 0; k3 < 3; k3++) shared += t.idx[t.ptr[bb] + k2] == t.idx[t.ptr[b] + k3];
+                put(bb, k - t.ptr[b], shared > 1);
             }
     }
     return true;
@@ -411,8 +427,8 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         else if (!a.list_cap) a.list_cap = 512;
         // large runs of the third form take the fourth (one workgroup per CU, flip waves fed by service waves);
         // small ones would leave most of its slots empty
-        const bool v4 = dec->path == 3 && switches().flip_kernel != 3 && !switches().flip_prof &&
-                        a.n_shots >= (uint64_t)device_cu_count() * 256 && flip4_slots(dec->nbt3, a.list_cap, 8) >= 65;
+        const bool v4 = dec->path == 3 && switches().flip_kernel != 3 &&
+                        a.n_shots >= (uint64_t)device_cu_count() * 256 && flip4_slots(dec->nbt3, a.list_cap, 4) >= 33;
         // HBM scratch pieces: one parked word and one flip log per shot in flight
         const size_t pieces = v4 ? flip4_scratch_pieces() : (size_t)(dec->path == 3 ? flip3_max_blocks() : flip2_max_blocks(g)) * 8;
         if (!a.errors_out) {

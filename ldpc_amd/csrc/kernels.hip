@@ -926,12 +926,29 @@ __device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg
         flog[nfl] = (uint16_t)b;                               // output ^= e_b (flip.rs:30) is deferred: log the flip
     }
     wave_order();
-    // both slots re-evaluate their bit against the new syndrome and rewrite its F bit
-    const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
-    const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
-    lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
-    lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
-    const uint32_t contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
+    // Both slots re-evaluate their bit against the new syndrome.  One of a neighbour's checks (word 3 of its record)
+    // changed by this flip, so its mask bit changes only if the count now sits at the threshold on the side it came
+    // from (count == 1 + that check); the record's flag covers the bits for which that does not hold.  Few lanes
+    // write, so the mask update costs the LDS little.
+    uint32_t contrib = 0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const uint4 &r = s ? r1 : r0;
+        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16)),
+                       wc = *(const uint32_t *)(Sg + (r.w >> 16));
+        const uint32_t conn = (wc >> (r.w & 31)) & 1u;
+        const uint32_t cnt = ((wa >> (r.y & 31)) & 1u) + ((wb >> (r.z & 31)) & 1u) + conn;
+        const bool fl = cnt >= 2;                              // flip.rs:41 for three checks
+        // (cnt == 1 + conn <=> the other two checks hold exactly one unsatisfied: the compiler reads the third
+        // word only in the lanes that write.  Measured against hand-made schedules -- all six reads up front, or
+        // both slots' first two reads then both third reads -- this one is the fastest under flip4_kernel's load:
+        // 7.2e7 shots/s at C2 against 6.6e7 and 6.5e7)
+        if ((r.x & 0x100u) || cnt == 1u + conn) {
+            const uint32_t m = one << (r.x & 31);
+            lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
+            if (fl) contrib |= 1u << (r.x >> 22);
+        }
+    }
     fs2 |= half_row_or_u32(contrib);
     nfl += one;
     wave_order();
@@ -1056,7 +1073,7 @@ __host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32
     return 34 + (uint32_t)(sizeof(Flip4Ctl) / 8) + helpers * (list_cap / 4);
 }
 
-template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
+template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
 {
     extern __shared__ uint64_t lds[];
     constexpr uint32_t NH = 16 - NF;
@@ -1103,7 +1120,11 @@ template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGra
         uint32_t *cnt_lds = &ctl->cnt[h];
         uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
         uint32_t idle = 0;
+        unsigned long long p_t0 = 0, p_busy = 0, p_start = 0;
+        if (PROF) p_start = __builtin_amdgcn_s_memtime();
         for (;;) {
+            if (PROF && p_t0) p_busy += __builtin_amdgcn_s_memtime() - p_t0;
+            p_t0 = 0;
             if (__hip_atomic_load(&ctl->n_output, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= count) break;
             if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             // a finished shot first (its slot is then reused), else a free slot while shots remain
@@ -1130,6 +1151,7 @@ template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGra
                 continue;
             }
             idle = 0;
+            if (PROF) p_t0 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint64_t *S = state + (size_t)slot * per_shot;
             if (from == F4_DONE) {
@@ -1164,6 +1186,9 @@ template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGra
             if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
             if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
             if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+            // diagnostics (LDPC_HIP_FLIP_PROF): service waves' busy ticks in the low half of a spare counter, their
+            // total ticks in the high half (units of 2^10 ticks)
+            if (PROF) atomicAdd(&a.counters[CNT_ZFAIL], (p_busy >> 10) | ((__builtin_amdgcn_s_memtime() - p_start) >> 10) << 32);
         }
         return;
     }
@@ -1175,7 +1200,13 @@ template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGra
     uint16_t *const waste = log_of(F4_MAX_SLOTS + wave);
     uint16_t *flog = waste;
     const uint32_t step_cap = 18 * g.m + 64;   // flips (<= m, each lowers the syndrome weight) + window retirements of one shot
+    unsigned long long p_iter = 0, p_live = 0, p_start = 0;
+    if (PROF) p_start = __builtin_amdgcn_s_memtime();
     for (;;) {
+        if (PROF) {
+            p_iter++;
+            p_live += (unsigned long long)__builtin_popcountll(__ballot(fs2 != 0 && gl == 0));
+        }
         if (__ballot(fs2 == 0)) {
             // ---- some group has nothing to flip: hand finished shots back, take prepared ones
             const bool finished = fs2 == 0 && slot != NONE;
@@ -1254,6 +1285,10 @@ template <int NF> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGra
             if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
+    }
+    if (PROF && lane == 0 && a.counters) {   // flip waves: loop passes, live groups summed over passes, ticks
+        atomicAdd(&a.counters[CNT_CAPPED], p_iter | p_live << 32);
+        atomicAdd(&a.counters[CNT_XFAIL], __builtin_amdgcn_s_memtime() - p_start);
     }
 }
 
@@ -2493,24 +2528,33 @@ uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf)
 
 uint32_t flip4_scratch_pieces() { return device_cu_count() * F4_LOGS; }
 
+typedef void (*flip4_fn)(DeviceGraph, Nb3Table, FlipArgs, uint32_t);
+static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
+{
+    switch (nf) {
+    case 4: return flip4_kernel<4>;
+    case 6: return flip4_kernel<6>;
+    case 7: return flip4_kernel<7>;
+    case 8: return prof ? flip4_kernel<8, true> : flip4_kernel<8>;
+    case 9: return prof ? flip4_kernel<9, true> : flip4_kernel<9>;
+    case 10: return flip4_kernel<10>;
+    default: return nullptr;
+    }
+}
+
 hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
-    uint32_t nf = 8;
-    if (switches().flip_nf >= 4 && switches().flip_nf <= 12) nf = (uint32_t)switches().flip_nf;
+    if (a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
+    // flip waves of the 16: measured at C2 8 -> 7.2e7, 9 -> 7.6e7 shots/s, 10 -> the service waves do not keep up
+    // (LDPC_HIP_FLIP_NF: A/B aid); fewer when the LDS holds fewer slots than their groups plus one per service wave
+    uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 9u;
+    while (nf > 4 && (!flip4_kernel_for(nf, false) || flip4_slots(nb, a.list_cap, nf) < nf * 8 + (16 - nf))) nf--;
+    const flip4_fn k = flip4_kernel_for(nf, switches().flip_prof);
     const uint32_t n_slots = flip4_slots(nb, a.list_cap, nf);
-    if (n_slots < nf * 8 + 1 || a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
+    if (!k || n_slots < nf * 8 + 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, 16 - nf) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(device_cu_count(), (a.n_shots + 63) / 64);
-    void (*k)(DeviceGraph, Nb3Table, FlipArgs, uint32_t) = flip4_kernel<8>;
-    switch (nf) {   // (A/B aid: LDPC_HIP_FLIP_NF)
-    case 4: k = flip4_kernel<4>; break;
-    case 6: k = flip4_kernel<6>; break;
-    case 7: k = flip4_kernel<7>; break;
-    case 9: k = flip4_kernel<9>; break;
-    case 10: k = flip4_kernel<10>; break;
-    default: nf = 8; break;
-    }
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (switches().debug) std::fprintf(stderr, "[ldpc_hip] flip4: %u flip waves, %u slots, lds %zu B, grid %u\n", nf, n_slots, lds, grid);

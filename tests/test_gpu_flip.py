@@ -70,6 +70,37 @@ def test_flip_matches_oracle(n, m, dv, dc, p, shots):
     assert cnt[CNT_UNDETECTED] == fails - det and cnt[CNT_WORK] == flips
 
 
+@pytest.mark.parametrize("n,m,dv,dc,p,shots", [(10000, 5000, 3, 6, 0.02, 70001), (1200, 900, 3, 4, 0.02, 200000),
+                                               (10000, 5000, 3, 6, 0.0004, 66000), (15000, 7500, 3, 6, 0.015, 66000)])
+def test_flip_large_runs_take_the_service_wave_form_and_change_nothing(monkeypatch, n, m, dv, dc, p, shots):
+    """Runs of 65536 shots or more on regular codes of bit degree 3 go through flip4_kernel (flip waves fed by
+    service waves); smaller ones, and LDPC_HIP_FLIP_KERNEL=v3, through flip3_kernel.  Every recorded word must be the
+    same, with and without the caller's error buffer, and equal to the oracle's (flip.rs:21-43) on a sample;
+    counters equal to the oracle's over the whole run."""
+    code = LinearCode.random_regular_code(n, m, dv, dc, seed=1)
+    oc = oracle_code(code)
+    dec = FlipDecoder(code)
+    first = 12345
+    de, ds, do = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u64((shots, nwords(n)))
+    cnt = dec.mc_run(p, SEED, first, shots, de, ds, do)
+    do_b = dev_u64((shots, nwords(n)))
+    cnt_b = dec.mc_run(p, SEED, first, shots, None, None, do_b)     # parked words in the library's scratch
+    assert (cnt_b == cnt).all() and bool((do_b == do).all())
+    monkeypatch.setenv("LDPC_HIP_FLIP_KERNEL", "v3")
+    de3, ds3, do3 = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u64((shots, nwords(n)))
+    cnt3 = dec.mc_run(p, SEED, first, shots, de3, ds3, do3)
+    monkeypatch.delenv("LDPC_HIP_FLIP_KERNEL")
+    assert (cnt3 == cnt).all()
+    assert bool((de3 == de).all()) and bool((ds3 == ds).all()) and bool((do3 == do).all())
+    ref = oc.mc_flip(p, SEED, first, shots, nthreads=16)
+    assert (cnt == ref).all(), (cnt, ref)
+    ge, gs, go = host_u64(de), host_u64(ds), host_u64(do)
+    for i in list(range(0, shots, max(shots // 150, 1))) + [shots - 1]:
+        e = orc.sample_bsc_words(SEED, first + i, p, n)
+        o, _, _ = oc.flip_decode_words(e)
+        assert (ge[i] == e).all() and (gs[i] == oc.syndrome_words(e)).all() and (go[i] == o).all()
+
+
 def test_flip_irregular_and_ragged():
     rng = np.random.default_rng(3)
     shapes = [(1, 0), (1, 1), (63, 10), (64, 64), (65, 33), (129, 200), (300, 7)]
