@@ -10,14 +10,22 @@ batched I/O", the algorithmic bytes the roofline figure is priced on).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--shots-per-step B]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; shots are sharded by
-global shot index (weak scaling: B shots per GPU per step), no data-path
-collective; the u64 counters are all-reduced over RCCL after the timed region.
-Rank 0 prints one JSON line.
+N > 1: one rank per GPU under torch.distributed.run -- started by the caller, or,
+when RANK is not set, by this script itself before anything touches the GPU
+(`python bench.py --gpus 8` works on its own); shots are sharded by global shot
+index (weak scaling: B shots per GPU per step), no data-path collective; the u64
+counters are all-reduced over RCCL after the timed region.  Rank 0 prints one
+JSON line.
+
+LDPC_BENCH_BACKEND=gloo rehearses the multi-rank path where there are fewer GPUs
+than ranks; LDPC_BENCH_STUB=1 replaces the GPU step by a constant (CPU test of the
+launch / reduce / print logic only, tests/test_bench_launch.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -63,16 +71,31 @@ def cpu_baseline(code, budget_s=25.0):
     }, cnt
 
 
-def measured_traffic(shots_per_launch):
-    """HBM-side bytes per launch from the rocprofv3 PMC passes of this same command
-    (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE), kept in profiles/r01_flip_pmc.json;
-    scaled to this run's shots per launch.  None when no profile is on record."""
+FLIP_PMC = "profiles/r02_flip_pmc.json"
+BP_PMC = "profiles/r01_bp_pmc.json"
+
+
+def recorded_traffic(shots_per_launch):
+    """HBM-side bytes per launch, NOT measured in this run: the per-shot figure of the rocprofv3 PMC passes over this
+    same command (fabric read + write requests of the flip kernel, kept in FLIP_PMC) times this run's shots per
+    launch.  Returns (bytes, source label); (None, None) when no profile is on record."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_flip_pmc.json")) as f:
+        with open(os.path.join(ROOT, FLIP_PMC)) as f:
             prof = json.load(f)
-        return prof["traffic_bytes_per_shot"] * shots_per_launch
+        return prof["traffic_bytes_per_shot"] * shots_per_launch, "%s x shots per launch (replayed, not a counter of this run)" % FLIP_PMC
     except Exception:
-        return None
+        return None, None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run and relay rank 0's
+    line.  Runs before this process touches torch.cuda / HIP (a process that holds the GPU must not exec)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def bp_line(code, shots=1 << 23):
@@ -87,7 +110,7 @@ def bp_line(code, shots=1 << 23):
     gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_bp_pmc.json")) as f:
+        with open(os.path.join(ROOT, BP_PMC)) as f:
             traffic = json.load(f)["traffic_over_algorithmic"] * int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges()
     except Exception:
         pass
@@ -95,7 +118,8 @@ def bp_line(code, shots=1 << 23):
             "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<6,3>", "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "%s: measured ratio x this run's algorithmic bytes (replayed, not a counter of this run)" % BP_PMC}}
 
 
 def css_line(shots=1 << 23):
@@ -154,44 +178,57 @@ def main():
                          "(Monte-Carlo mode, counters only), e.g. for its scaling over N GPUs")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # no launcher above us: become one (nothing here has touched the GPU yet); a failing rank fails the run
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     # one rank per GPU; LDPC_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
-    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    stub = os.environ.get("LDPC_BENCH_STUB") == "1"   # CPU test of the launch / reduce / print logic: no GPU step
+    local_dev = 0 if stub else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
         else:
             dist.init_process_group(backend=backend)
-    torch.cuda.set_device(local_dev)
+    if not stub:
+        torch.cuda.set_device(local_dev)
 
     import ldpc_amd
     from ldpc_amd import FlipDecoder, LinearCode
     from ldpc_amd.dist import all_reduce_counters
 
-    ldpc_amd.set_device(local_dev)
-    code = LinearCode.random_regular_code(N_BITS, N_CHECKS, DV, DC, seed=CODE_SEED)
-    dec = FlipDecoder(code)
     B = args.shots_per_step
     wn, wm = ldpc_amd.nwords(N_BITS), ldpc_amd.nwords(N_CHECKS)
     bytes_per_shot = 2 * wn * 8 + wm * 8
     use_bp = args.decoder == "bp"
-    if not use_bp:
-        d_err = torch.empty((B, wn), dtype=torch.int64, device="cuda")
-        d_syn = torch.empty((B, wm), dtype=torch.int64, device="cuda")
-        d_out = torch.empty((B, wn), dtype=torch.int64, device="cuda")
-
-    if use_bp:
-        from ldpc_amd import BpDecoder
-        bp_dec = BpDecoder(code, P, 100)
+    code = dec = None
+    if not stub:
+        ldpc_amd.set_device(local_dev)
+        code = LinearCode.random_regular_code(N_BITS, N_CHECKS, DV, DC, seed=CODE_SEED)
+        dec = FlipDecoder(code)
+        if not use_bp:
+            d_err = torch.empty((B, wn), dtype=torch.int64, device="cuda")
+            d_syn = torch.empty((B, wm), dtype=torch.int64, device="cuda")
+            d_out = torch.empty((B, wn), dtype=torch.int64, device="cuda")
+        else:
+            from ldpc_amd import BpDecoder
+            bp_dec = BpDecoder(code, P, 100)
 
     def step(s):
         first = (s * world + rank) * B        # global shot index: disjoint across ranks and steps
+        if stub:
+            c = np.zeros(ldpc_amd.N_COUNTERS, dtype=np.uint64)
+            c[ldpc_amd.CNT_SHOTS] = B
+            return c
         if use_bp:
             return bp_dec.mc_run(P, NOISE_SEED, first, B)
         return dec.mc_run(P, NOISE_SEED, first, B, d_err, d_syn, d_out)
@@ -199,7 +236,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     for s in range(args.warmup):
         step(s)
@@ -209,16 +247,17 @@ def main():
     kernel_ms = []
     for s in range(args.steps):
         counters += step(args.warmup + s)
-        kernel_ms.append(ldpc_amd.last_kernel_ms())
+        kernel_ms.append(1.0 if stub else ldpc_amd.last_kernel_ms())
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" and not stub else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    counters = all_reduce_counters(counters)
+    counters = all_reduce_counters(counters, device="cpu" if stub or backend != "nccl" else None)
 
     if rank == 0:
+        traffic, traffic_source = recorded_traffic(B)
         total_shots = B * world * args.steps
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = B * bytes_per_shot / avg_kernel_s / 1e9
@@ -244,12 +283,26 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                "kernel": "flip2_kernel", "kernel_ms": avg_kernel_s * 1e3,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "stub" if stub else ldpc_amd.last_kernel_name(), "kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
             },
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
         }
+        if stub:
+            line["data"] = "stub (no GPU step: launch / reduce / print logic only)"
+            print(json.dumps(line), flush=True)
+        elif True:
+            finish_line(line, args, world, use_bp, code, counters, avg_kernel_s)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def finish_line(line, args, world, use_bp, code, counters, avg_kernel_s):
+    """Rank 0: the N = 1 extras (cpu_baseline, secondary BP / C5 / CSS objects) or the BP step's own roofline, then print."""
+    import ldpc_amd
+    if True:
         if not args.no_cpu_baseline and world == 1 and not use_bp:   # reported at N = 1 only
             cb, _ = cpu_baseline(code)
             line["cpu_baseline"] = cb
@@ -269,18 +322,12 @@ def main():
                                 "kernel": "bp_kernel<6,3>", "kernel_ms": avg_kernel_s * 1e3,
                                 "algorithmic_bytes_per_shot_iteration": 32 * code.num_edges()}
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_bp_pmc.json")) as f:
+                with open(os.path.join(ROOT, BP_PMC)) as f:
                     line["roofline"]["traffic"] = json.load(f)["traffic_over_algorithmic"] * alg
+                    line["roofline"]["traffic_source"] = "%s: measured ratio x algorithmic bytes (replayed, not a counter of this run)" % BP_PMC
             except Exception:
                 pass
-            line.pop("cpu_baseline", None)
-            line.pop("bp", None)
-            line.pop("bp_c5", None)
-            line.pop("css", None)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

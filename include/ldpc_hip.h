@@ -79,6 +79,9 @@ int ldpc_set_stream(void *hip_stream);
 /* Duration of the decoding kernels of the most recent call on this thread,
  * measured with hipEvents on the launch stream (bench.py roofline). */
 double ldpc_last_kernel_ms(void);
+/* Name of the decoding kernel this thread launched last (the library picks among several forms of a decoder by
+ * code and batch size; bench.py names the one it timed).  No counterpart in the reference. */
+const char *ldpc_last_kernel_name(void);
 /* The LDPC_HIP_* environment variables (A/B, test and profiling switches; none is needed in production) are read
  * once, when the library first needs one.  A test that changes one afterwards calls this to have them read again.
  * No counterpart in the reference (it has no configuration).  Not to be called while other
@@ -199,6 +202,13 @@ int ldpc_bp_decode(ldpc_bp_decoder *dec, size_t len, const size_t *positions, si
 int ldpc_bp_correction_for_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_syndromes,
                                  uint64_t *d_corrections_out, uint32_t *d_iterations_out,
                                  double *d_posteriors_out);
+/* The same with the check -> bit messages at stop as a further output: d_check_messages_out [n_shots][E] f64 (may be
+ * NULL), edge order = Edges (edges.rs:23-29); the values `Messages::update_checks` last wrote
+ * (belief_propagation.rs:156-163), 0.0 for a shot that stopped before its first update (:68-76).  A parity / debug
+ * output: with max_iterations = 1, 2, ... it shows the messages after each iteration. */
+int ldpc_bp_correction_for_batch_messages(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_syndromes,
+                                          uint64_t *d_corrections_out, uint32_t *d_iterations_out,
+                                          double *d_posteriors_out, double *d_check_messages_out);
 int ldpc_bp_decode_batch(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_words_in,
                          uint64_t *d_words_out, uint32_t *d_iterations_out);
 /* Monte-Carlo with BSC(noise_probability) errors; the decoder keeps the prior it

@@ -71,6 +71,7 @@ def lib():
         "ldpc_set_stream": (i, [vp]),
         "ldpc_last_kernel_ms": (dbl, []),
         "ldpc_debug_reload_switches": (None, []),
+        "ldpc_last_kernel_name": (C.c_char_p, []),
         "ldpc_code_create": (i, [sz, sz, vp, vp, pp]),
         "ldpc_code_hamming": (i, [pp]),
         "ldpc_code_repetition": (i, [sz, pp]),
@@ -110,6 +111,7 @@ def lib():
         "ldpc_bp_correction_for": (i, [vp, sz, vp, sz, vp, C.POINTER(sz)]),
         "ldpc_bp_decode": (i, [vp, sz, vp, sz, vp, C.POINTER(sz)]),
         "ldpc_bp_correction_for_batch": (i, [vp, sz, vp, vp, vp, vp]),
+        "ldpc_bp_correction_for_batch_messages": (i, [vp, sz, vp, vp, vp, vp, vp]),
         "ldpc_bp_decode_batch": (i, [vp, sz, vp, vp, vp]),
         "ldpc_bp_mc_run": (i, [vp, dbl, u64, u64, sz, vp, vp]),
         "ldpc_bp_destroy": (None, [vp]),
@@ -182,6 +184,10 @@ def set_device(device):
 
 def last_kernel_ms():
     return float(lib().ldpc_last_kernel_ms())
+
+
+def last_kernel_name():
+    return lib().ldpc_last_kernel_name().decode("ascii", "replace")
 
 
 def reload_switches():
@@ -581,7 +587,12 @@ class BpDecoder:
         return [int(x) for x in out[: k.value]]
 
     def correction_for_batch(self, n_shots, d_syndromes, d_corrections_out=None, d_iterations_out=None,
-                             d_posteriors_out=None):
+                             d_posteriors_out=None, d_check_messages_out=None):
+        if d_check_messages_out is not None:   # [n_shots][E] f64: check -> bit messages at stop (parity output)
+            _check(lib().ldpc_bp_correction_for_batch_messages(self._h, int(n_shots), _ptr(d_syndromes), _ptr(d_corrections_out),
+                                                               _ptr(d_iterations_out), _ptr(d_posteriors_out),
+                                                               _ptr(d_check_messages_out)))
+            return
         _check(lib().ldpc_bp_correction_for_batch(self._h, int(n_shots), _ptr(d_syndromes), _ptr(d_corrections_out),
                                                   _ptr(d_iterations_out), _ptr(d_posteriors_out)))
 

@@ -480,7 +480,7 @@ struct BpRun {
     const uint64_t *words_in = nullptr, *synd_in = nullptr;
     uint64_t *corr_out = nullptr;
     uint32_t *iters_out = nullptr;
-    double *post_out = nullptr;
+    double *post_out = nullptr, *chk_out = nullptr;
     uint8_t *failed_out = nullptr;
     const ldpc_code *logicals = nullptr;
     uint32_t share = 1;   // this run has 1 / share of the GPU's workgroup slots (CSS halves side by side)
@@ -557,6 +557,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.corr_out = r.corr_out;
     a.iters_out = r.iters_out;
     a.post_out = r.post_out;
+    a.chk_out = r.chk_out;
     a.failed_out = r.failed_out;
     a.counters = dec->counters.as<unsigned long long>();
     a.queue = dec->counters.as<unsigned long long>() + LDPC_COUNTERS;   // zeroed with the counters
@@ -688,6 +689,8 @@ LDPC_CATCH
 double ldpc_last_kernel_ms(void) { return g_last_ms; }
 
 void ldpc_debug_reload_switches(void) { reload_switches(); }
+
+const char *ldpc_last_kernel_name(void) { return last_launched_kernel(); }
 
 // ---- LinearCode -----------------------------------------------------------
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
@@ -1146,6 +1149,25 @@ try {
     r.corr_out = d_corrections_out;
     r.iters_out = d_iterations_out;
     r.post_out = d_posteriors_out;
+    r.gap = make_gap_table(0.0);
+    return run_bp(dec, r, nullptr);
+}
+LDPC_CATCH
+
+int ldpc_bp_correction_for_batch_messages(ldpc_bp_decoder *dec, size_t n_shots, const uint64_t *d_syndromes,
+                                          uint64_t *d_corrections_out, uint32_t *d_iterations_out,
+                                          double *d_posteriors_out, double *d_check_messages_out)
+try {
+    if (!dec || (n_shots && !d_syndromes)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    BpRun r;
+    r.source = SRC_SYNDROMES;
+    r.test = TEST_NONE;
+    r.n_shots = n_shots;
+    r.synd_in = d_syndromes;
+    r.corr_out = d_corrections_out;
+    r.iters_out = d_iterations_out;
+    r.post_out = d_posteriors_out;
+    r.chk_out = d_check_messages_out;
     r.gap = make_gap_table(0.0);
     return run_bp(dec, r, nullptr);
 }

@@ -24,6 +24,8 @@ namespace ldpc {
 
 namespace {
 
+thread_local const char *g_kernel_name = "";   // host: the decoding kernel this thread launched last
+
 constexpr int CNT_SHOTS = 0, CNT_FAIL = 1, CNT_DET = 2, CNT_UNDET = 3, CNT_WORK = 4, CNT_CAPPED = 5, CNT_XFAIL = 6,
               CNT_ZFAIL = 7;
 
@@ -1741,6 +1743,8 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
                             for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) l += chkm[(size_t)g.t_edge[k] * 64 + lane];
                         a.post_out[myi * n + b] = l;
                     }
+                if (a.chk_out)   // check -> bit messages at stop (belief_propagation.rs:156-163), Edges order; 0.0 before any update (:68-76)
+                    for (uint32_t e = wv; e < g.E; e += NW) a.chk_out[myi * g.E + e] = fresh ? 0.0 : chkm[(size_t)e * 64 + lane];
                 if (wv == 0) {
                     if (a.iters_out) a.iters_out[myi] = iter;
                     if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
@@ -2081,6 +2085,9 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_harvest_words(DeviceGraph g, 
                 for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) l += G.chkm[(size_t)g.t_edge[k] * 64 + lane];
             a.post_out[myi * n + b] = l;
         }
+    if (a.chk_out && done)
+        for (uint32_t e = part * BPS_WAVES + wv; e < g.E; e += parts * BPS_WAVES)
+            a.chk_out[myi * g.E + e] = fresh ? 0.0 : G.chkm[(size_t)e * 64 + lane];
 }
 
 // one wave per group: counters and per-shot outputs of the slots that stop, slots freed; alive: add the
@@ -2351,6 +2358,7 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
         hipError_t e = hipFuncSetAttribute((const void *)flip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    g_kernel_name = "flip_kernel";
     hipLaunchKernelGGL(flip_kernel, dim3(grid_for(a.n_shots, wpb, 256 * 8)), dim3(wpb * 64), lds, st, g, a);
     return hipGetLastError();
 }
@@ -2416,6 +2424,7 @@ hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs 
     const size_t lds = flip2_lds_bytes(g, lanes, a.list_cap);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_blocks_for(g, a.list_cap));
+    g_kernel_name = "flip2_kernel";
     if (nb.dvp == 3) {
         if (lanes == 8) launch_flip2_t<3, 8>(g, nb, a, grid, lds, st);
         else launch_flip2_t<3, 16>(g, nb, a, grid, lds, st);
@@ -2455,6 +2464,8 @@ Switches read_switches()
     return s;
 }
 }  // namespace
+
+const char *last_launched_kernel() { return g_kernel_name; }
 
 const Switches &switches()
 {
@@ -2512,6 +2523,7 @@ hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
         std::fprintf(stderr, "[ldpc_hip] flip3: lds %zu B, %u blocks per CU (occupancy API: %d)\n", lds, per_cu, occ);
     }
     const uint32_t grid = grid_for(a.n_shots, 8, device_cu_count() * per_cu);
+    g_kernel_name = "flip3_kernel";
     if (prof) hipLaunchKernelGGL(flip3_kernel<true>, dim3(grid), dim3(64), lds, st, g, nb, a);
     else hipLaunchKernelGGL(flip3_kernel<false>, dim3(grid), dim3(64), lds, st, g, nb, a);
     return hipGetLastError();
@@ -2558,6 +2570,9 @@ hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (switches().debug) std::fprintf(stderr, "[ldpc_hip] flip4: %u flip waves, %u slots, lds %zu B, grid %u\n", nf, n_slots, lds, grid);
+    static const char *const names[] = {"flip4_kernel<4>", "flip4_kernel<5>", "flip4_kernel<6>", "flip4_kernel<7>", "flip4_kernel<8>",
+                                        "flip4_kernel<9>", "flip4_kernel<10>"};
+    g_kernel_name = names[nf - 4];
     hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, g, nb, a, n_slots);
     return hipGetLastError();
 }
@@ -2592,6 +2607,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
                      hipStream_t st)
 {
     if (!a.n_shots || !groups) return hipSuccess;
+    g_kernel_name = dc == 6 && dv == 3 ? "bp_kernel<6,3>" : dc == 4 && dv == 3 ? "bp_kernel<4,3>" : dc == 7 ? "bp_kernel<7,*>" : "bp_kernel<0,*>";
     hipLaunchKernelGGL(bp_kernel_for(dc, dv), dim3(groups), dim3(64 * waves), 0, st, g, a);
     return hipGetLastError();
 }
@@ -2644,6 +2660,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
     // Measured at C5: no gain from the skew (a check-update wave keeps its SIMD only 22 % busy, so the check update
     // needs all four wave slots of a SIMD to itself); one set by default, LDPC_HIP_BP_STREAM_SKEW=1 for experiments
     const bool skew = !resume && switches().bp_stream_skew;
+    if (!resume) g_kernel_name = "bps_iterate (streamed form)";
     uint32_t set0[2] = {0, skew ? (groups + 1) / 2 : groups}, setn[2] = {skew ? (groups + 1) / 2 : groups, skew ? groups / 2 : 0};
     unsigned long long alive[2] = {0, 0};
     bool wants_checks[2] = {true, true};
@@ -2730,7 +2747,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         if ((err = hipMemcpyAsync(s.moves, mv.data(), mv.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
         uint32_t cparts = std::max<uint32_t>(1, (uint32_t)(8 * cus) / keep);
         cparts = std::min<uint32_t>(cparts, std::max<uint32_t>(1, (g.E + BPS_WAVES - 1) / BPS_WAVES));
-        hipLaunchKernelGGL(bps_compact, dim3(keep * cparts), blk, 0, st, g, a, s, cparts, (const uint32_t *)s.moves, a.post_out ? 1 : 0);
+        hipLaunchKernelGGL(bps_compact, dim3(keep * cparts), blk, 0, st, g, a, s, cparts, (const uint32_t *)s.moves, (a.post_out || a.chk_out) ? 1 : 0);
         if ((err = hipMemcpyAsync(s.act, act.data(), (size_t)groups * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
         if ((err = hipMemcpyAsync(s.fresh, fr.data(), (size_t)groups * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return err;
         if ((err = hipStreamSynchronize(st)) != hipSuccess) return err;   // (the host vectors go out of scope)

@@ -33,6 +33,8 @@ struct Switches {
     bool debug = false;               // LDPC_HIP_DEBUG
 };
 const Switches &switches();
+// name of the decoding kernel this thread launched last (bench.py's roofline object names it)
+const char *last_launched_kernel();
 void reload_switches();
 
 enum NoiseSource : int {
@@ -100,6 +102,7 @@ struct BpArgs {
     uint64_t *corr_out;         // [n_shots][Wn] or null
     uint32_t *iters_out;        // [n_shots]     or null
     double *post_out;           // [n_shots][n]  or null
+    double *chk_out;            // [n_shots][E]  or null: check -> bit messages at stop, Edges order (debug / parity)
     uint8_t *failed_out;        // [n_shots]     or null
     unsigned long long *counters;
     // logical test matrix (rows = logical generators), TEST_LOGICAL only

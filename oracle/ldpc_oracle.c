@@ -386,6 +386,21 @@ void orc_bp_decode_words(const orc_code *c, double p, uint32_t max_iter, const u
     free(s);
 }
 
+/* orc_bp_correction_for over a batch of syndromes, shots spread over OpenMP threads (the wide GPU parity tests):
+ * syn [nshots][wm], corr [nshots][wn], iters [nshots], post [nshots][n] or NULL, chk [nshots][E] or NULL. */
+void orc_bp_correction_for_batch(const orc_code *c, double p, uint32_t max_iter, uint64_t nshots, const uint64_t *syn,
+                                 uint64_t *corr, uint32_t *iters, double *post, double *chk, int nthreads)
+{
+    size_t wn = nwords(c->n) ? nwords(c->n) : 1, wm = nwords(c->m) ? nwords(c->m) : 1;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)nshots; i++)
+        orc_bp_correction_for(c, p, max_iter, syn + (size_t)i * wm, corr + (size_t)i * wn, iters + i,
+                              post ? post + (size_t)i * c->n : NULL, chk ? chk + (size_t)i * (size_t)c->E : NULL);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Noise.  Distribution per binary_symmetric_channel.rs:35-43 and            */
 /* depolarizing.rs:34-48; the stream is this project's specification         */

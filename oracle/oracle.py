@@ -52,6 +52,7 @@ def lib():
         L.orc_flip_decode_words.argtypes = [vp, vp, vp, vp, vp]
         L.orc_bp_correction_for.argtypes = [vp, dbl, u32, vp, vp, vp, vp, vp]
         L.orc_bp_decode_words.argtypes = [vp, dbl, u32, vp, vp, vp]
+        L.orc_bp_correction_for_batch.argtypes = [vp, dbl, u32, u64, vp, vp, vp, vp, vp, C.c_int]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_gap_table.argtypes = [dbl, vp]
         L.orc_sample_bsc_words.argtypes = [u64, u64, dbl, u32, vp]
@@ -180,6 +181,19 @@ class Code:
         if want_messages:
             return corr[: nwords(self.n)], int(it.value), post[: self.n], chk[: self.E]
         return corr[: nwords(self.n)], int(it.value), post[: self.n]
+
+    def bp_correction_for_batch(self, p, max_iter, syn_words, want_post=False, want_messages=False, nthreads=1):
+        """orc_bp_correction_for on every row of syn_words [shots][nwords(m)], shots spread over threads.
+        Returns corrections [shots][nwords(n)], iterations [shots], posteriors or None, check messages or None."""
+        syn = np.ascontiguousarray(syn_words, dtype=np.uint64)
+        shots = syn.shape[0]
+        corr = np.zeros((shots, max(nwords(self.n), 1)), dtype=np.uint64)
+        its = np.zeros(shots, dtype=np.uint32)
+        post = np.zeros((shots, max(self.n, 1)), dtype=np.float64) if want_post else None
+        chk = np.zeros((shots, max(self.E, 1)), dtype=np.float64) if want_messages else None
+        lib().orc_bp_correction_for_batch(self.h, float(p), int(max_iter), shots, _p(syn), _p(corr), _p(its),
+                                          _p(post) if want_post else None, _p(chk) if want_messages else None, int(nthreads))
+        return corr, its, post, chk
 
     def bp_decode_words(self, p, max_iter, msg_words):
         msg = np.ascontiguousarray(msg_words, dtype=np.uint64)
