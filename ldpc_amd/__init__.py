@@ -106,6 +106,7 @@ def lib():
         "ldpc_flip_decode": (i, [vp, sz, vp, sz, vp, C.POINTER(sz)]),
         "ldpc_flip_decode_batch": (i, [vp, sz, vp, vp, vp, vp]),
         "ldpc_flip_mc_run": (i, [vp, dbl, u64, u64, sz, vp, vp, vp, vp]),
+        "ldpc_flip_mc_run_noalloc": (i, [vp, dbl, u64, u64, sz, vp, vp, vp, vp]),
         "ldpc_flip_destroy": (None, [vp]),
         "ldpc_bp_create": (i, [vp, dbl, sz, pp]),
         "ldpc_bp_correction_for": (i, [vp, sz, vp, sz, vp, C.POINTER(sz)]),
@@ -540,6 +541,14 @@ class FlipDecoder:
                                       cnt.ctypes.data_as(C.c_void_p), _ptr(d_errors_out), _ptr(d_syndromes_out),
                                       _ptr(d_words_out)))
         return cnt
+
+    def mc_run_noalloc(self, probability, seed, first_shot, n_shots, d_counters_out, d_errors_out=None,
+                       d_syndromes_out=None, d_words_out=None):
+        """ldpc_flip_mc_run_noalloc: no device allocation, no synchronisation; the counters go to the device buffer
+        d_counters_out ([8] u64) and are valid after the stream has been synchronised."""
+        _check(lib().ldpc_flip_mc_run_noalloc(self._h, _pval(probability), int(seed), int(first_shot), int(n_shots),
+                                              _ptr(d_counters_out), _ptr(d_errors_out), _ptr(d_syndromes_out),
+                                              _ptr(d_words_out)))
 
     def __str__(self):
         return "Flip decoder"

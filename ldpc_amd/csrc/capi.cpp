@@ -1123,6 +1123,81 @@ try {
 }
 LDPC_CATCH
 
+// The Monte-Carlo call for callers that cannot allocate (HIP graph capture, serving loops): the same kernels as
+// ldpc_flip_mc_run with every piece of device scratch -- counters, parked input words, flip logs -- taken from
+// the library's static device array (kernels.hip `scratch`, 64 MiB per GPU), no hipMalloc / hipFree, no event, no
+// synchronisation.  The counters land in a device buffer of the caller when the stream reaches that point.
+int ldpc_flip_mc_run_noalloc(ldpc_flip_decoder *dec, double probability, uint64_t seed, uint64_t first_shot, size_t n_shots,
+                             uint64_t *d_counters_out, uint64_t *d_errors_out, uint64_t *d_syndromes_out, uint64_t *d_words_out)
+try {
+    if (!dec || !d_counters_out) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    std::lock_guard<std::mutex> lock(dec->mu);
+    {
+        std::lock_guard<std::mutex> code_lock(dec->code.mu);
+        int current = 0;
+        HIP_TRY(hipGetDevice(&current));
+        if (!dec->code.uploaded || dec->path == 0)
+            return fail(LDPC_ERR_BAD_ARG, "ldpc_flip_mc_run_noalloc: the handle is not set up on a device yet (graph and tables are "
+                                          "uploaded by its first ordinary call: make one ldpc_flip_mc_run / ldpc_flip_decode_batch first)");
+        if (current != dec->code.device)
+            return fail(LDPC_ERR_BAD_ARG, "this handle's buffers live on device " + std::to_string(dec->code.device) +
+                                              ", the calling thread's current device is " + std::to_string(current));
+    }
+    const DeviceGraph &g = dec->code.dg;
+    unsigned char *base = nullptr;
+    size_t bytes = 0;
+    HIP_TRY(noalloc_scratch(&base, &bytes));
+    // layout: 256 bytes of counters, then one piece per shot in flight (parked word + flip log), 8 pieces per block
+    const size_t head = 256;
+    FlipArgs a{};
+    a.source = SRC_BSC;
+    a.seed = seed;
+    a.first_shot = first_shot;
+    a.n_shots = n_shots;
+    a.errors_out = d_errors_out;
+    a.synd_out = d_syndromes_out;
+    a.words_out = d_words_out;
+    a.gap = make_gap_table(probability);
+    a.expected_weight = (double)dec->code.host.len() * probability;
+    a.max_flips = 0xFFFFFFFFu;
+    a.counters = (unsigned long long *)base;
+    a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
+    HIP_TRY(hipMemsetAsync(base, 0, head, g_stream));   // the array keeps the last call's contents: the counters start at zero
+    if (dec->path == 1) {
+        const size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
+        if (33 * 8 + per_wave > 160 * 1024)
+            return fail(LDPC_ERR_CAPACITY, "flip decoder: per-shot state of " + std::to_string(per_wave) +
+                                               " bytes does not fit the 160 KiB LDS of a CU");
+        HIP_TRY(launch_flip(g, a, g_stream));
+    } else {
+        const size_t word_bytes = std::max<size_t>(words_for(g.n), 1) * 8;
+        const size_t log_bytes = (size_t)a.flip_log_cap * (dec->path == 3 ? 2 : 4);
+        const size_t per_block = 8 * ((word_bytes + 255) / 256 * 256 + (log_bytes + 255) / 256 * 256);
+        const size_t blocks = (bytes - head) / per_block;
+        if (blocks == 0)
+            return fail(LDPC_ERR_CAPACITY, "ldpc_flip_mc_run_noalloc: one block's scratch of " + std::to_string(per_block) +
+                                               " bytes exceeds the static array of " + std::to_string(bytes) + " bytes (code too large)");
+        const uint32_t block_cap = (uint32_t)std::min<size_t>(blocks, 1u << 20);
+        // parked words [block_cap * 8][word], then logs [block_cap * 8][log]: both strides as the kernels index them
+        a.o_scratch = (uint64_t *)(base + head);
+        const size_t log_off = (head + (size_t)block_cap * 8 * word_bytes + 255) & ~(size_t)255;
+        a.flip_log = (uint32_t *)(base + log_off);
+        if (log_off + (size_t)block_cap * 8 * log_bytes > bytes)
+            return fail(LDPC_ERR_CAPACITY, "ldpc_flip_mc_run_noalloc: scratch layout exceeds the static array");
+        if (dec->path == 3) {
+            a.list_cap = flip3_list_cap(a.expected_weight);
+            HIP_TRY(launch_flip3(g, dec->nbt3, a, false, g_stream, block_cap));
+        } else {
+            a.list_cap = flip2_list_cap(a.expected_weight);
+            HIP_TRY(launch_flip2(g, dec->nbt, a, g_stream, block_cap));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_counters_out, base, sizeof(uint64_t) * LDPC_COUNTERS, hipMemcpyDeviceToDevice, g_stream));
+    return LDPC_OK;
+}
+LDPC_CATCH
+
 void ldpc_flip_destroy(ldpc_flip_decoder *dec) { delete dec; }
 
 // ---- BpDecoder ------------------------------------------------------------

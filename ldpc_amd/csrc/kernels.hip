@@ -2417,13 +2417,14 @@ static void launch_flip2_t(const DeviceGraph &g, const NbTable &nb, const FlipAr
 #undef LDPC_FLIP2
 }
 
-hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st)
+hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st, uint32_t block_cap)
 {
     if (!a.n_shots) return hipSuccess;
     const uint32_t lanes = flip2_lanes_per_shot(g);
     const size_t lds = flip2_lds_bytes(g, lanes, a.list_cap);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_blocks_for(g, a.list_cap));
+    uint32_t grid = grid_for(a.n_shots, 64 / lanes, flip2_blocks_for(g, a.list_cap));
+    if (block_cap) grid = std::min(grid, block_cap);
     g_kernel_name = "flip2_kernel";
     if (nb.dvp == 3) {
         if (lanes == 8) launch_flip2_t<3, 8>(g, nb, a, grid, lds, st);
@@ -2510,7 +2511,36 @@ uint32_t flip3_list_cap(double expected_weight)
 // upper bound on the blocks of any flip3 launch (scratch sizing): 8 one-wave blocks per SIMD
 uint32_t flip3_max_blocks() { return device_cu_count() * 32u; }
 
-hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st)
+// ---------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (ldpc_flip_mc_run_noalloc): a file-scope device array, one copy
+// per GPU for the life of the process.  In host code `scratch` is only a stand-in for the symbol: its device address
+// on the current GPU comes from hipGetSymbolAddress, once per device, and everything (memset, kernel arguments,
+// copies) uses that pointer.
+// ---------------------------------------------------------------------------
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+hipError_t noalloc_scratch(unsigned char **ptr, size_t *bytes)
+{
+    static unsigned char *per_device[64];
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // this GPU's copy of the array (no allocation)
+        if (e != hipSuccess) return e;
+        per_device[dev] = (unsigned char *)p;
+    }
+    *ptr = per_device[dev];
+    *bytes = NOALLOC_SCRATCH_BYTES;
+    return hipSuccess;
+}
+
+hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st, uint32_t block_cap)
 {
     if (!a.n_shots) return hipSuccess;
     const size_t lds = flip3_lds_bytes(nb, a.list_cap);
@@ -2522,7 +2552,8 @@ hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)flip3_kernel<false>, 64, lds);
         std::fprintf(stderr, "[ldpc_hip] flip3: lds %zu B, %u blocks per CU (occupancy API: %d)\n", lds, per_cu, occ);
     }
-    const uint32_t grid = grid_for(a.n_shots, 8, device_cu_count() * per_cu);
+    uint32_t grid = grid_for(a.n_shots, 8, device_cu_count() * per_cu);
+    if (block_cap) grid = std::min(grid, block_cap);   // (the caller's scratch holds fewer blocks: each works more batches)
     g_kernel_name = "flip3_kernel";
     if (prof) hipLaunchKernelGGL(flip3_kernel<true>, dim3(grid), dim3(64), lds, st, g, nb, a);
     else hipLaunchKernelGGL(flip3_kernel<false>, dim3(grid), dim3(64), lds, st, g, nb, a);

@@ -144,7 +144,10 @@ size_t flip3_lds_bytes(const Nb3Table &t, uint32_t list_cap);
 uint32_t flip3_list_cap(double expected_weight);
 uint32_t flip3_max_blocks();
 uint32_t device_cu_count();
-hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st);
+// block_cap (0: none): at most this many blocks (the scratch given in `a` is indexed by block)
+hipError_t launch_flip3(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, bool prof, hipStream_t st, uint32_t block_cap = 0);
+// the static device array behind ldpc_flip_mc_run_noalloc: its address on the current GPU and its size
+hipError_t noalloc_scratch(unsigned char **ptr, size_t *bytes);
 // fourth form (large runs): one 1024-thread workgroup per CU, flip waves + service waves
 uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf);
 uint32_t flip4_scratch_pieces();   // pieces (parked word / flip log) of HBM scratch a launch may index
@@ -161,7 +164,7 @@ hipError_t launch_sample_depol(const GapTable &gap, uint32_t n, uint64_t seed, u
 hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_t *d_words, uint64_t *d_synd,
                            hipStream_t st);
 hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st);
-hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st);
+hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st, uint32_t block_cap = 0);
 // dc / dv: the common check / bit degree of a regular code, 0 when degrees vary
 // groups = workgroups (64 shot slots each), waves = wavefronts per workgroup sharing a group
 hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uint32_t waves, int dc, int dv,
