@@ -458,9 +458,16 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
         return LDPC_OK;
     }
     size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
-    if (33 * 8 + per_wave > 160 * 1024)
-        return fail(LDPC_ERR_CAPACITY, "flip decoder: per-shot state of " + std::to_string(per_wave) +
-                                           " bytes does not fit the 160 KiB LDS of a CU");
+    if (33 * 8 + per_wave > 160 * 1024) {
+        // the state of a shot does not fit the LDS of a CU (n = 10^6): wave-per-shot kernel with the state in HBM
+        HIP_TRY(dec->o_scratch.reserve(flip_big_scratch_bytes(g, a.n_shots)));
+        KernelTimer timer;
+        HIP_TRY(launch_flip_big(g, a, dec->o_scratch.as<uint64_t>(), g_stream));
+        timer.stop_and_store();
+        if (counters_out) return read_counters(dec->counters, counters_out);
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return LDPC_OK;
+    }
     KernelTimer timer;
     HIP_TRY(launch_flip(g, a, g_stream));
     timer.stop_and_store();
@@ -1167,8 +1174,8 @@ try {
     if (dec->path == 1) {
         const size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
         if (33 * 8 + per_wave > 160 * 1024)
-            return fail(LDPC_ERR_CAPACITY, "flip decoder: per-shot state of " + std::to_string(per_wave) +
-                                               " bytes does not fit the 160 KiB LDS of a CU");
+            return fail(LDPC_ERR_CAPACITY, "ldpc_flip_mc_run_noalloc: per-shot state of " + std::to_string(per_wave) +
+                                               " bytes does not fit the LDS of a CU and the static array is not sized for it");
         HIP_TRY(launch_flip(g, a, g_stream));
     } else {
         const size_t word_bytes = std::max<size_t>(words_for(g.n), 1) * 8;

@@ -323,6 +323,158 @@ __global__ __launch_bounds__(256) void flip_kernel(DeviceGraph g, FlipArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Flip decoder for codes whose per-shot state does not fit the LDS of a CU (n = 10^6: 312 KB): the same wave-per-shot
+// algorithm as flip_kernel with S, F and O in HBM / L2 (`big` scratch, one slice per wave) and two summary levels
+// over F so that the lowest flippable bit costs three dependent reads, not a scan: FS bit w = F word w may be
+// non-zero, FSS bit v = FS word v may be non-zero.  A summary bit can be stale (set over an empty word): the scan
+// clears it and goes on.  Only this wave touches its slice; lanes meet through device-scope atomics and loads (a
+// plain load could be served by a vector-L1 line that an atomic of another lane has since changed in L2).
+// ---------------------------------------------------------------------------
+__device__ inline uint64_t ld64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t getbit_g(const uint64_t *w, uint32_t i) { return (uint32_t)(ld64(w + (i >> 6)) >> (i & 63)) & 1u; }
+__device__ inline void xorbit_g(uint64_t *w, uint32_t i) { atomicXor((unsigned long long *)(w + (i >> 6)), 1ull << (i & 63)); }
+__device__ inline void orbit_g(uint64_t *w, uint32_t i) { atomicOr((unsigned long long *)(w + (i >> 6)), 1ull << (i & 63)); }
+__device__ inline void clrbit_g(uint64_t *w, uint32_t i) { atomicAnd((unsigned long long *)(w + (i >> 6)), ~(1ull << (i & 63))); }
+
+__host__ __device__ inline size_t flip_big_words(uint32_t n, uint32_t m)
+{
+    const size_t Wn = (n + 63) / 64, Wm = (m + 63) / 64, W1 = (Wn + 63) / 64, W2 = (W1 + 63) / 64;
+    return Wm + 2 * Wn + W1 + W2 + 8;
+}
+
+__global__ __launch_bounds__(256) void flip_big_kernel(DeviceGraph g, FlipArgs a, uint64_t *big)
+{
+    __shared__ uint32_t q[65];
+    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = a.gap.q[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64, W1 = (Wn + 63) / 64, W2 = (W1 + 63) / 64;
+    const uint64_t gw = (uint64_t)blockIdx.x * wpb + wave, waves = (uint64_t)gridDim.x * wpb;
+    uint64_t *S = big + gw * flip_big_words(g.n, g.m), *F = S + Wm, *O = F + Wn, *FS = O + Wn, *FSS = FS + W1;
+    const uint32_t state_words = Wm + 2 * Wn + W1 + W2;
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+
+    // unsatisfied checks of bit b > deg / 2 (flip.rs:41)
+    auto flippable = [&](uint32_t b) -> bool {
+        const uint32_t k0 = g.t_ptr[b], k1 = g.t_ptr[b + 1];
+        uint32_t unsat = 0;
+        for (uint32_t k = k0; k < k1; k++) unsat += getbit_g(S, g.t_idx[k]);
+        return unsat > (k1 - k0) / 2;
+    };
+    auto set_f = [&](uint32_t b) {
+        orbit_g(F, b);
+        orbit_g(FS, b >> 6);
+        orbit_g(FSS, b >> 12);
+    };
+
+    for (uint64_t i = gw; i < a.n_shots; i += waves) {
+        const uint64_t shot = a.first_shot + i;
+        for (uint32_t w = lane; w < state_words; w += 64) S[w] = 0;
+        // 1. error word -> O, syndrome by toggling the checks of every error bit
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            const uint32_t nb = bits_in_word(g.n, w);
+            uint64_t x;
+            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
+            else {
+                x = a.words_in[i * Wn + w];
+                if (nb < 64) x &= (1ull << nb) - 1;
+            }
+            O[w] = x;
+            if (a.errors_out) a.errors_out[i * Wn + w] = x;
+        }
+        wave_sync();   // the zeroes and O are in memory before the atomics below
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            uint64_t x = ld64(O + w);
+            while (x) {
+                const uint32_t b = (w << 6) + (uint32_t)__builtin_ctzll(x);
+                x &= x - 1;
+                for (uint32_t k = g.t_ptr[b]; k < g.t_ptr[b + 1]; k++) xorbit_g(S, g.t_idx[k]);
+            }
+        }
+        wave_sync();
+        if (a.synd_out)
+            for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = ld64(S + w);
+        // 2. flippable mask: only a bit on an unsatisfied check can be flippable
+        for (uint32_t w = lane; w < Wm; w += 64) {
+            uint64_t x = ld64(S + w);
+            while (x) {
+                const uint32_t c = (w << 6) + (uint32_t)__builtin_ctzll(x);
+                x &= x - 1;
+                for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) {
+                    const uint32_t b = g.h_idx[e];
+                    if (flippable(b)) set_f(b);
+                }
+            }
+        }
+        wave_sync();
+        // 3. serial flips, lowest index first (flip.rs:27,35-43); at most m flips, each lowers the syndrome weight
+        uint32_t nflips = 0;
+        for (uint64_t guard = 0; guard < 40ull * g.m + 4ull * Wn + 64; guard++) {   // (flips + stale summary bits; never spin on a bug)
+            // first set bit of FSS -> FS word -> F word
+            int32_t v = -1;
+            for (uint32_t base = 0; base < W2 && v < 0; base += 64) {
+                const uint64_t x = base + lane < W2 ? ld64(FSS + base + lane) : 0;
+                const uint64_t nz = __ballot(x != 0);
+                if (nz) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(nz);
+                    v = (int32_t)((base + l) * 64 + (uint32_t)__builtin_ctzll(readlane64(x, l)));
+                }
+            }
+            if (v < 0) break;                                              // find_flippable == None
+            const uint64_t fs = ld64(FS + v);
+            if (!fs) {                                                     // stale: nothing under this FS word
+                if (lane == 0) clrbit_g(FSS, (uint32_t)v);
+                wave_sync();
+                continue;
+            }
+            const uint32_t w = (uint32_t)v * 64 + (uint32_t)__builtin_ctzll(fs);
+            const uint64_t fw = ld64(F + w);
+            if (!fw) {                                                     // stale: the F word emptied since
+                if (lane == 0) clrbit_g(FS, w);
+                wave_sync();
+                continue;
+            }
+            const uint32_t b = w * 64 + (uint32_t)__builtin_ctzll(fw);
+            nflips++;
+            const uint32_t k0 = g.t_ptr[b], deg = g.t_ptr[b + 1] - k0;
+            if (lane == 0) xorbit_g(O, b);                                 // flip.rs:30
+            for (uint32_t kk = lane; kk < deg; kk += 64) xorbit_g(S, g.t_idx[k0 + kk]);   // flip.rs:29
+            wave_sync();
+            // refresh F for every bit that shares a check with b (b itself included)
+            for (uint32_t i2 = 0; i2 < deg; i2++) {
+                const uint32_t c = g.t_idx[k0 + i2];
+                const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+                for (uint32_t j = lane; j < dc; j += 64) {
+                    const uint32_t bb = g.h_idx[e0 + j];
+                    if (flippable(bb)) set_f(bb);
+                    else clrbit_g(F, bb);
+                }
+            }
+            wave_sync();
+        }
+        // 4. failure test (all-zero codeword) and outputs
+        uint64_t anyo = 0, anys = 0;
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            const uint64_t x = ld64(O + w);
+            anyo |= x;
+            if (a.words_out) a.words_out[i * Wn + w] = x;
+        }
+        for (uint32_t w = lane; w < Wm; w += 64) anys |= ld64(S + w);
+        const bool fail = __ballot(anyo != 0) != 0, det = __ballot(anys != 0) != 0;
+        if (a.flips_out && lane == 0) a.flips_out[i] = nflips;
+        c_shots++; c_fail += fail; c_det += det; c_undet += fail && !det; c_flips += nflips;
+        wave_sync();
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+        if (c_undet) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)c_undet);
+        if (c_flips) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_flips);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Flip decoder, fast path.  One wave carries FOUR shots: the serial flip loop
 // of a shot only ever touches the <= K bits around the flipped bit, so a group
 // of 16 lanes per shot runs it (K slots = one or more rounds of 16), and the
@@ -2360,6 +2512,22 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
     }
     g_kernel_name = "flip_kernel";
     hipLaunchKernelGGL(flip_kernel, dim3(grid_for(a.n_shots, wpb, 256 * 8)), dim3(wpb * 64), lds, st, g, a);
+    return hipGetLastError();
+}
+
+// waves (= shots in flight) of a flip_big_kernel launch, and the scratch they index
+uint32_t flip_big_waves(uint64_t n_shots) { return (uint32_t)std::min<uint64_t>(n_shots, (uint64_t)device_cu_count() * 8); }
+size_t flip_big_scratch_bytes(const DeviceGraph &g, uint64_t n_shots)
+{
+    return ((size_t)flip_big_waves(n_shots) + 3) / 4 * 4 * flip_big_words(g.n, g.m) * 8;
+}
+
+hipError_t launch_flip_big(const DeviceGraph &g, const FlipArgs &a, uint64_t *big, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    const uint32_t blocks = (flip_big_waves(a.n_shots) + 3) / 4;
+    g_kernel_name = "flip_big_kernel";
+    hipLaunchKernelGGL(flip_big_kernel, dim3(blocks), dim3(256), 0, st, g, a, big);
     return hipGetLastError();
 }
 

@@ -164,6 +164,9 @@ hipError_t launch_sample_depol(const GapTable &gap, uint32_t n, uint64_t seed, u
 hipError_t launch_syndrome(const DeviceGraph &g, uint64_t n_shots, const uint64_t *d_words, uint64_t *d_synd,
                            hipStream_t st);
 hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st);
+// per-shot state in HBM (codes beyond the LDS of a CU): `big` = flip_big_scratch_bytes(g, n_shots) bytes
+size_t flip_big_scratch_bytes(const DeviceGraph &g, uint64_t n_shots);
+hipError_t launch_flip_big(const DeviceGraph &g, const FlipArgs &a, uint64_t *big, hipStream_t st);
 hipError_t launch_flip2(const DeviceGraph &g, const NbTable &nb, const FlipArgs &a, hipStream_t st, uint32_t block_cap = 0);
 // dc / dv: the common check / bit degree of a regular code, 0 when degrees vary
 // groups = workgroups (64 shot slots each), waves = wavefronts per workgroup sharing a group

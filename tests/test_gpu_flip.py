@@ -49,7 +49,10 @@ def test_flip_mc_counters_c1_full():
                                                (10000, 5000, 3, 6, 0.2, 24),
                                                # largest sizes: near the LDS limit of the fast path (4 shots per wave), and
                                                # the generic kernel near its own (one shot's state per wave, 125 of 160 KiB)
-                                               (60000, 30000, 3, 6, 0.01, 8), (400000, 200000, 3, 6, 0.005, 4)])
+                                               (60000, 30000, 3, 6, 0.01, 8), (400000, 200000, 3, 6, 0.005, 4),
+                                               # BASELINE configs[4]: the state of a shot (312 KB) exceeds the LDS of a CU and
+                                               # lives in HBM (flip_big_kernel)
+                                               (1000000, 500000, 3, 6, 0.005, 4), (1000000, 500000, 3, 6, 0.02, 2)])
 def test_flip_matches_oracle(n, m, dv, dc, p, shots):
     code = LinearCode.random_regular_code(n, m, dv, dc, seed=1)
     oc = oracle_code(code)
@@ -166,12 +169,23 @@ def test_single_process_multi_device_runs_sum_to_the_single_run():
         mc_run_multi(code, [99], 0.04, 5, 0, 10, "flip")
 
 
-def test_flip_beyond_the_lds_limit_is_refused():
-    """A shot whose state (syndrome + two words of n bits) does not fit a CU's 160 KiB of LDS: LDPC_ERR_CAPACITY, no
-    launch (such codes are served by BP only)."""
+def test_flip_beyond_the_lds_limit_runs_from_hbm_and_only_the_no_alloc_call_refuses_it():
+    """n = 10^6 (BASELINE configs[4]): a shot's state does not fit a CU's 160 KiB of LDS; FlipDecoder::decode has no
+    size limit (flip.rs:21-33), so the library keeps that state in HBM (flip_big_kernel; parity in
+    test_flip_matches_oracle).  What truly cannot be served is the same code through ldpc_flip_mc_run_noalloc, whose
+    static scratch array is not sized for it: LDPC_ERR_CAPACITY, no launch."""
+    import torch
     import ldpc_amd
     code = LinearCode.random_regular_code(1000000, 500000, 3, 6, seed=1)
     dec = FlipDecoder(code)
+    cnt = dec.mc_run(0.001, SEED, 0, 8)
+    assert cnt[CNT_SHOTS] == 8
+    # decode_batch on the decoded words: idempotent (nothing left to flip)
+    do = dev_u64((8, nwords(1000000)))
+    dec.mc_run(0.001, SEED, 0, 8, None, None, do)
+    do2, df = dev_u64((8, nwords(1000000))), dev_u32((8,))
+    dec.decode_batch(8, do, do2, None, df)
+    assert bool((do2 == do).all()) and int(df.sum()) == 0
     with pytest.raises(ldpc_amd.LdpcError) as e:
-        dec.mc_run(0.01, SEED, 0, 4)
-    assert e.value.status == ldpc_amd.ERR_CAPACITY and "LDS" in str(e.value)
+        dec.mc_run_noalloc(0.001, SEED, 0, 4, torch.zeros(8, dtype=torch.int64, device="cuda"))
+    assert e.value.status == ldpc_amd.ERR_CAPACITY
