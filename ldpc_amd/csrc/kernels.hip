@@ -901,8 +901,10 @@ __host__ __device__ constexpr uint32_t flip3_hdr_words(uint32_t list_cap) { retu
 // window w holds a flippable bit), the same value in every lane.  i = the shot's index within the call.
 __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table &nbt, const FlipArgs &a, const uint32_t *q,
                                             uint16_t *list, uint32_t LIST_CAP, uint32_t *cnt_lds, uint64_t *S, uint64_t *O,
-                                            uint64_t i, uint32_t lane)
+                                            uint64_t i, uint32_t lane, unsigned long long *stamp = nullptr)
 {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (stamp) ts0 = __builtin_amdgcn_s_memtime();
     const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
     const uint32_t Sw = nbt.sw, per_shot = Sw + nbt.windows * 8;
     const uint4 *nb = nbt.rec;
@@ -935,6 +937,7 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         }
     }
     wave_sync();   // O is read back from memory below (overflow path) and by the output stage
+    if (stamp) ts1 = __builtin_amdgcn_s_memtime();
     const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
     if (total <= LIST_CAP) {
         // pass 1, syndrome: toggle the three checks of every error bit (slot 0 of its row)
@@ -952,6 +955,7 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
                 }
         }
         wave_order();
+        if (stamp) ts2 = __builtin_amdgcn_s_memtime();
         // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
         // slot reads the spare check and is never flippable
         constexpr uint32_t P2 = 8;
@@ -1013,7 +1017,12 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
     wave_order();
     if (a.synd_out)
         for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
-    return (uint32_t)wave_or64(summary);
+    const uint32_t all = (uint32_t)wave_or64(summary);
+    if (stamp) {   // diagnostics: noise + list, pass 1, pass 2 + syndrome output
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        stamp[0] += ts1 - ts0; stamp[1] += ts2 - ts1; stamp[2] += ts3 - ts2;
+    }
+    return all;
 }
 
 // Output of one finished shot, by one whole wave: the decoded word = parked input word (E, HBM) with the nf logged
@@ -1054,16 +1063,29 @@ __device__ inline uint32_t flip3_output_shot(const DeviceGraph &g, const Nb3Tabl
 // each shot is flipped (flip.rs:27-30), or, when the scanned window of its mask holds none, the window is retired.
 // Sg / Fg: the group's shot state in LDS; fs2: summary of F (0: nothing to do -- the group then works the spare row
 // and changes nothing); nfl: flips so far = position in the flip log.
-__device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg, char *Fg, uint16_t *flog, uint32_t gl,
-                                  uint32_t &fs2, uint32_t &nfl)
+template <bool STAMP = false, int VARIANT = 1>
+__device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char *Sg, char *Fg, char *log_base, uint32_t log_off,
+                                  uint32_t gl, uint32_t &fs2, uint32_t &nfl, unsigned long long *stamp = nullptr)
 {
+    // STAMP (diagnostics): cycles of the four stretches of a pass -- mask window read, search, row load, evaluation
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (STAMP) t0 = __builtin_amdgcn_s_memtime();
     const uint32_t Fg_addr = lds_addr_of(Fg);
     const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
     const uint64_t x = *(const uint64_t *)(Fg + (w2 << 6) + gl * 8);
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    // lowest set bit of the lane's 64 mask bits; all ones when there is none
-    const uint32_t clo = lo ? (uint32_t)__builtin_ctz(lo) : NONE, chi = hi ? (uint32_t)__builtin_ctz(hi) | 32u : NONE;
-    const uint32_t c = (clo < chi ? clo : chi) | (gl << 6);
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (STAMP) {
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    // lowest set bit of the lane's 64 mask bits as a position in the window (v_ffbl_b32 gives all ones for zero, and
+    // all ones stay all ones under the OR with the lane's base)
+    uint32_t clo, chi;
+    asm("v_ffbl_b32 %0, %1" : "=v"(clo) : "v"(lo));
+    asm("v_ffbl_b32 %0, %1" : "=v"(chi) : "v"(hi));
+    clo |= gl << 6;
+    chi |= (gl << 6) | 32u;
+    const uint32_t c = clo < chi ? clo : chi;
     const uint32_t mpos = half_row_min2_u32(c);
     const bool found = fs2 != 0 && mpos != NONE;
     // the window is empty, or the bit about to be flipped is its only one: retire it (a neighbour that
@@ -1071,13 +1093,24 @@ __device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg
     const uint32_t inwin = half_row_add_u32((uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi));
     if (inwin <= 1) fs2 &= fs2 - 1;
     const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
-    const uint4 r0 = nbl[(size_t)b << 4], r1 = nbl[((size_t)b << 4) + 1];
+    if (STAMP) {
+        uint32_t bb = b;
+        asm volatile("" : "+v"(bb));
+        t2 = __builtin_amdgcn_s_memtime();
+    }
+    // (uniform base + 32-bit lane offset: one address instruction per load; the table is at most 4 MiB)
+    const uint32_t roff = (b << 8) + gl * 32u;
+    uint4 r0 = *(const uint4 *)(nb_base + roff), r1 = *(const uint4 *)(nb_base + roff + 16);
+    if (STAMP) {
+        asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+        t3 = __builtin_amdgcn_s_memtime();
+    }
     const uint32_t one = found ? 1u : 0u;
     if (gl == 0) {                                             // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
         atomicXor((uint32_t *)(Sg + (r0.y >> 16)), one << (r0.y & 31));
         atomicXor((uint32_t *)(Sg + (r0.z >> 16)), one << (r0.z & 31));
         atomicXor((uint32_t *)(Sg + (r0.w >> 16)), one << (r0.w & 31));
-        flog[nfl] = (uint16_t)b;                               // output ^= e_b (flip.rs:30) is deferred: log the flip
+        *(uint16_t *)(log_base + (log_off + nfl * 2u)) = (uint16_t)b;   // output ^= e_b (flip.rs:30) is deferred: log the flip
     }
     wave_order();
     // Both slots re-evaluate their bit against the new syndrome.  One of a neighbour's checks (word 3 of its record)
@@ -1085,6 +1118,25 @@ __device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg
     // from (count == 1 + that check); the record's flag covers the bits for which that does not hold.  Few lanes
     // write, so the mask update costs the LDS little.
     uint32_t contrib = 0;
+    if (VARIANT == 0) {
+        // every slot reads its three checks and rewrites its mask bit (no branch, eight LDS operations per lane)
+        const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
+        const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
+        lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
+        lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
+        contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
+    } else if (VARIANT == 2) {
+        const uint32_t wa0 = *(const uint32_t *)(Sg + (r0.y >> 16)), wb0 = *(const uint32_t *)(Sg + (r0.z >> 16)),
+                       wc0 = *(const uint32_t *)(Sg + (r0.w >> 16)), wa1 = *(const uint32_t *)(Sg + (r1.y >> 16)),
+                       wb1 = *(const uint32_t *)(Sg + (r1.z >> 16)), wc1 = *(const uint32_t *)(Sg + (r1.w >> 16));
+        const uint32_t s0 = ((wa0 >> (r0.y & 31)) & 1u) + ((wb0 >> (r0.z & 31)) & 1u), s1 = ((wa1 >> (r1.y & 31)) & 1u) + ((wb1 >> (r1.z & 31)) & 1u);
+        const bool f0 = s0 + ((wc0 >> (r0.w & 31)) & 1u) >= 2, f1 = s1 + ((wc1 >> (r1.w & 31)) & 1u) >= 2;
+        // unchanged slots write with an empty mask: no branch, the LDS still sees every lane
+        const uint32_t m0 = ((r0.x & 0x100u) || s0 == 1u) ? one << (r0.x & 31) : 0u, m1 = ((r1.x & 0x100u) || s1 == 1u) ? one << (r1.x & 31) : 0u;
+        lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
+        lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
+        contrib = (f0 && m0 ? 1u << (r0.x >> 22) : 0u) | (f1 && m1 ? 1u << (r1.x >> 22) : 0u);
+    } else {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const uint4 &r = s ? r1 : r0;
@@ -1093,19 +1145,29 @@ __device__ inline void flip3_step(const uint4 *nbl, uint32_t dummy_row, char *Sg
         const uint32_t conn = (wc >> (r.w & 31)) & 1u;
         const uint32_t cnt = ((wa >> (r.y & 31)) & 1u) + ((wb >> (r.z & 31)) & 1u) + conn;
         const bool fl = cnt >= 2;                              // flip.rs:41 for three checks
-        // (cnt == 1 + conn <=> the other two checks hold exactly one unsatisfied: the compiler reads the third
-        // word only in the lanes that write.  Measured against hand-made schedules -- all six reads up front, or
-        // both slots' first two reads then both third reads -- this one is the fastest under flip4_kernel's load:
-        // 7.2e7 shots/s at C2 against 6.6e7 and 6.5e7)
+        // One of a neighbour's checks (word 3 of its record) changed by this flip, so its mask bit changes only if
+        // the count now sits at the threshold on the side it came from: cnt == 1 + conn, i.e. the other two checks
+        // hold exactly one unsatisfied (the compiler tests that and reads the third word only in the lanes that
+        // write); the record's flag covers the slots for which it does not hold (b itself, doubly connected bits).
+        // Measured at C2 under flip4_kernel against other schedules of the same work -- all six reads up front
+        // (6.6e7 shots/s), both slots' first two reads together and then the third reads (7.3e7), every lane
+        // rewriting its bit (VARIANT 0, 7.2e7): this slot-after-slot form is the fastest (7.8e7).
         if ((r.x & 0x100u) || cnt == 1u + conn) {
             const uint32_t m = one << (r.x & 31);
             lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
             if (fl) contrib |= 1u << (r.x >> 22);
         }
     }
+    }
     fs2 |= half_row_or_u32(contrib);
     nfl += one;
     wave_order();
+    if (STAMP) {
+        uint32_t f = fs2;
+        asm volatile("" : "+v"(f));
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3;
+    }
 }
 
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
@@ -1150,13 +1212,14 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
         uint32_t nfl = 0;
         {
             char *Sg = (char *)(state + (size_t)grp * per_shot), *Fg = Sg + (size_t)Sw * 8;
-            uint16_t *flog = (uint16_t *)a.flip_log + ((size_t)blockIdx.x * SPW + grp) * a.flip_log_cap;   // n < 2^16
-            const uint4 *nbl = nbt.rec + gl * 2;       // the lane's two slots of a row
+            // flip log of the group's shot (u16 entries: n < 2^16), as a byte offset from the block's first log
+            char *log_base = (char *)((uint16_t *)a.flip_log + (size_t)blockIdx.x * SPW * a.flip_log_cap);
+            const uint32_t log_off = grp * a.flip_log_cap * 2u;
             // every iteration flips a bit (at most m flips: each lowers the syndrome weight) or retires a window
             const uint32_t iter_cap = 18 * g.m + 64;
             for (uint32_t it = 0; it < iter_cap; it++) {
                 if (!__ballot(fs2 != 0)) break;                            // flip.rs:27 find_flippable == None, all shots
-                flip3_step(nbl, g.n, Sg, Fg, flog, gl, fs2, nfl);
+                flip3_step((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl);
                 if (PROF) n_iter++;
             }
         }
@@ -1274,7 +1337,7 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
         uint32_t *cnt_lds = &ctl->cnt[h];
         uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
         uint32_t idle = 0;
-        unsigned long long p_t0 = 0, p_busy = 0, p_start = 0;
+        unsigned long long p_t0 = 0, p_busy = 0, p_start = 0, p_svc[4] = {0, 0, 0, 0};
         if (PROF) p_start = __builtin_amdgcn_s_memtime();
         for (;;) {
             if (PROF && p_t0) p_busy += __builtin_amdgcn_s_memtime() - p_t0;
@@ -1309,12 +1372,15 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint64_t *S = state + (size_t)slot * per_shot;
             if (from == F4_DONE) {
+                unsigned long long to0 = 0;
+                if (PROF) to0 = __builtin_amdgcn_s_memtime();
                 const uint32_t rel = __builtin_amdgcn_readfirstlane(ctl->shot[slot]);
                 const uint32_t nfj = __builtin_amdgcn_readfirstlane(ctl->nfl[slot]), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
                 const uint32_t r = flip3_output_shot(g, nbt, a, S, err_words(slot, rel), log_of(slot), nf, lo + rel, lane);
                 c_shots++; c_fail += r & 1; c_det += (r >> 1) & 1; c_undet += r == 1; c_flips += nf;
                 wave_sync();
                 if (lane == 0) __hip_atomic_fetch_add(&ctl->n_output, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (PROF) p_svc[3] += __builtin_amdgcn_s_memtime() - to0;
             }
             // the next shot of the block goes into the slot, if there is one
             uint32_t rel = 0;
@@ -1325,7 +1391,8 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
                 if (lane == 0) __hip_atomic_store(&ctl->status[slot], F4_HELD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
             }
-            const uint32_t s = flip3_setup_shot(g, nbt, a, q, list, LIST_CAP, cnt_lds, S, err_words(slot, rel), lo + rel, lane);
+            const uint32_t s = flip3_setup_shot(g, nbt, a, q, list, LIST_CAP, cnt_lds, S, err_words(slot, rel), lo + rel, lane,
+                                                PROF ? p_svc : nullptr);
             if (lane == 0) {
                 ctl->shot[slot] = rel;
                 ctl->fs2[slot] = s;
@@ -1343,18 +1410,22 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
             // diagnostics (LDPC_HIP_FLIP_PROF): service waves' busy ticks in the low half of a spare counter, their
             // total ticks in the high half (units of 2^10 ticks)
             if (PROF) atomicAdd(&a.counters[CNT_ZFAIL], (p_busy >> 10) | ((__builtin_amdgcn_s_memtime() - p_start) >> 10) << 32);
+            if (PROF && blockIdx.x == 0 && h == 0 && c_shots)
+                printf("[flip4 prof] service wave, ticks per shot: noise + list %.0f, pass 1 %.0f, pass 2 %.0f, output %.0f\n",
+                       (double)p_svc[0] / c_shots, (double)p_svc[1] / c_shots, (double)p_svc[2] / c_shots, (double)p_svc[3] / c_shots);
         }
         return;
     }
     // ===================================================================== flip wave
     if (a.max_flips == 1) __builtin_amdgcn_s_setprio(3);   // (experiment) the serial chains win the issue arbitration
-    const uint4 *nbl = nbt.rec + gl * 2;
     uint32_t slot = NONE, fs2 = 0, nfl = 0, idle = 0, steps = 0;
     char *Sg = (char *)state, *Fg = Sg + (size_t)Sw * 8;
-    uint16_t *const waste = log_of(F4_MAX_SLOTS + wave);
-    uint16_t *flog = waste;
+    // flip logs as byte offsets from the block's first one (uniform base + 32-bit offset: F4_LOGS logs of < 2^17 bytes)
+    char *const log_base = (char *)log_of(0);
+    const uint32_t waste = (F4_MAX_SLOTS + wave) * a.flip_log_cap * 2u;
+    uint32_t log_off = waste;
     const uint32_t step_cap = 18 * g.m + 64;   // flips (<= m, each lowers the syndrome weight) + window retirements of one shot
-    unsigned long long p_iter = 0, p_live = 0, p_start = 0;
+    unsigned long long p_iter = 0, p_live = 0, p_start = 0, p_stamp[4] = {0, 0, 0, 0};
     if (PROF) p_start = __builtin_amdgcn_s_memtime();
     for (;;) {
         if (PROF) {
@@ -1375,7 +1446,7 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
                 if (finished) {
                     // the group's no-op rounds must not touch the slot's log (its next shot writes there)
                     slot = NONE;
-                    flog = waste;
+                    log_off = waste;
                     nfl = 0;
                 }
             }
@@ -1416,7 +1487,7 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
                     nfl = 0;
                     Sg = (char *)(state + (size_t)slot * per_shot);
                     Fg = Sg + (size_t)Sw * 8;
-                    flog = log_of(slot);
+                    log_off = slot * a.flip_log_cap * 2u;
                     steps = 0;
                     // (a shot with nothing to flip has fs2 == 0 and is handed back on the next pass)
                 }
@@ -1434,7 +1505,7 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
             }
             idle = 0;
         }
-        flip3_step(nbl, g.n, Sg, Fg, flog, gl, fs2, nfl);
+        flip3_step<PROF>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
         if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
             if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
@@ -1443,6 +1514,12 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
     if (PROF && lane == 0 && a.counters) {   // flip waves: loop passes, live groups summed over passes, ticks
         atomicAdd(&a.counters[CNT_CAPPED], p_iter | p_live << 32);
         atomicAdd(&a.counters[CNT_XFAIL], __builtin_amdgcn_s_memtime() - p_start);
+        // stretches of a pass, 16 bits each, in units of 2^-4 of the wave's total stamped ticks ... kept simple: the
+        // shares in 1/1000 packed into the low half of the detected-failure counter's spare neighbour
+        const unsigned long long tot = p_stamp[0] + p_stamp[1] + p_stamp[2] + p_stamp[3];
+        if (tot && blockIdx.x == 0 && wave == 0)
+            printf("[flip4 prof] pass stretches: window read %.3f, search %.3f, row load %.3f, evaluation %.3f of %.1f ticks per pass\n",
+                   (double)p_stamp[0] / tot, (double)p_stamp[1] / tot, (double)p_stamp[2] / tot, (double)p_stamp[3] / tot, (double)tot / p_iter);
     }
 }
 
