@@ -72,7 +72,27 @@ def cpu_baseline(code, budget_s=25.0):
 
 
 FLIP_PMC = "profiles/r02_flip_pmc.json"
-BP_PMC = "profiles/r01_bp_pmc.json"
+BP_PMC = "profiles/r02_bp_pmc.json"
+C5_PMC = "profiles/r02_bp_c5_pmc.json"
+CSS_PMC = "profiles/r02_css_pmc.json"
+
+
+def replayed_ratio(path):
+    """traffic / algorithmic bytes of a recorded rocprofv3 PMC run of the same workload (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            return float(json.load(f)["traffic_over_algorithmic"])
+    except Exception:
+        return None
+
+
+def bp_roofline(alg_bytes, ms, pmc):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    ratio = replayed_ratio(pmc)
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None if ratio is None else ratio * alg_bytes,
+            "traffic_source": None if ratio is None else "%s: measured traffic / algorithmic ratio x this run's algorithmic bytes "
+                                                         "(replayed, not a counter of this run)" % pmc}
 
 
 def recorded_traffic(shots_per_launch):
@@ -107,19 +127,10 @@ def bp_line(code, shots=1 << 23):
     dec.mc_run(P, NOISE_SEED, 1 << 40, 8192)
     cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
     ms = ldpc_amd.last_kernel_ms()
-    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, BP_PMC)) as f:
-            traffic = json.load(f)["traffic_over_algorithmic"] * int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges()
-    except Exception:
-        pass
     return {"workload": "same code and channel, BpDecoder f64, max 100 iterations, %d shots" % shots,
-            "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<6,3>", "kernel_ms": ms,
+            "shots_per_s": shots / (ms * 1e-3), "kernel": ldpc_amd.last_kernel_name(), "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "%s: measured ratio x this run's algorithmic bytes (replayed, not a counter of this run)" % BP_PMC}}
+            "roofline": bp_roofline(int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges(), ms, BP_PMC)}
 
 
 def css_line(shots=1 << 23):
@@ -135,17 +146,15 @@ def css_line(shots=1 << 23):
     dec.mc_run(0.01, NOISE_SEED, 1 << 40, 4096)
     cnt = dec.mc_run(0.01, NOISE_SEED, 0, shots)
     ms = ldpc_amd.last_kernel_ms()
-    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges / (ms * 1e-3) / 1e9
     return {"workload": "configs[2]: CSS hypergraph-product code, 625 qubits (Hx, Hz 300 x 625, row weight 7), depolarizing "
                         "p=0.01, BP f64 max 100 iterations on each half, logical failure test, %d shots" % shots,
             "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<7,-4> (+ streamed tail)", "kernel_ms": ms,
             "iterations_per_shot_both_halves": int(cnt[ldpc_amd.CNT_WORK]) / shots,
             "logical_failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+            "roofline": bp_roofline(int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges, ms, CSS_PMC)}
 
 
-def bp_c5_line(shots=17664):
+def bp_c5_line(shots=70656):
     """Secondary measurement: configs[4], (3,6)-regular n = 10^6 (3 GB of f64 messages per 64-shot group: the
     streamed BP form, one grid-wide kernel per phase).  Time = hipEvents around the whole host-driven loop."""
     import ldpc_amd
@@ -155,14 +164,12 @@ def bp_c5_line(shots=17664):
     dec.mc_run(P, NOISE_SEED, 1 << 40, 64)
     cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
     ms = ldpc_amd.last_kernel_ms()
-    gbs = int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges() / (ms * 1e-3) / 1e9
     return {"workload": "configs[4]: random (3,6)-regular LDPC n=1000000 m=500000, BSC p=0.02, BpDecoder f64, max 100 "
                         "iterations, %d shots" % shots,
             "shots_per_s": shots / (ms * 1e-3), "kernels": "bps_iterate<6,3> + set-up / stop-test / harvest kernels",
             "loop_ms": ms, "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots,
             "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+            "roofline": bp_roofline(int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges(), ms, C5_PMC)}
 
 
 def main():
@@ -170,7 +177,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--shots-per-step", type=int, default=1 << 20, help="shots per GPU per step")
+    ap.add_argument("--shots-per-step", type=int, default=1 << 22, help="shots per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bp", action="store_true", help="skip the secondary BP measurement")
     ap.add_argument("--decoder", choices=("flip", "bp"), default="flip",

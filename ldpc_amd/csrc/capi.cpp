@@ -101,6 +101,15 @@ inline size_t words_for(size_t nbits) { return (nbits + 63) / 64; }
 
 bool valid_probability(double p) { return p >= 0.0 && p <= 1.0; }   // noise/mod.rs:40-46
 
+// A channel the device samplers can draw from: the gap table holds P(gap >= j) as floor(q^j 2^32) (DESIGN.md
+// "Noise specification"), so below about 1e-7 the sampled rate is off by more than 0.1 % and below 2^-32 it would
+// stick at 2^-32.  rand's Bernoulli (binary_symmetric_channel.rs:23-28) compares 64 bits; rather than sample a
+// different channel silently, such probabilities are refused (0 itself is exact: no draws).
+constexpr double MIN_SAMPLED_PROBABILITY = 1e-7;
+const char *const SAMPLED_PROBABILITY_MSG =
+    "probability is not 0 and below 1e-7: the 32-bit gap table of the device samplers cannot represent it to 0.1 %";
+bool samplable_probability(double p) { return p == 0.0 || p >= MIN_SAMPLED_PROBABILITY; }
+
 GapTable make_gap_table(double p)
 {
     GapTable t;
@@ -703,6 +712,7 @@ const char *ldpc_last_kernel_name(void) { return last_launched_kernel(); }
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
 try {
     if (!out || (!row_ptr && n_checks)) return fail(LDPC_ERR_BAD_ARG, "null argument");
+    if (n_checks && row_ptr[n_checks] > 0 && !col_idx) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (n_bits >= 0xFFFFFFFFull || n_checks >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "dimension exceeds 32 bits");
     std::vector<std::vector<uint32_t>> rows(n_checks);
     if (n_checks) {
@@ -978,6 +988,7 @@ int ldpc_bsc_sample_batch(double probability, size_t len, uint64_t seed, uint64_
                           uint64_t *d_words)
 try {
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
     if (n_shots && len && !d_words) return fail(LDPC_ERR_BAD_ARG, "null argument");
     KernelTimer timer;
@@ -991,6 +1002,7 @@ int ldpc_depolarizing_sample_batch(double probability, size_t len, uint64_t seed
                                    uint64_t *d_x_words, uint64_t *d_z_words)
 try {
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     if (len >= 0xFFFFFFFFull) return fail(LDPC_ERR_CAPACITY, "length exceeds 32 bits");
     if (n_shots && len && (!d_x_words || !d_z_words)) return fail(LDPC_ERR_BAD_ARG, "null argument");
     KernelTimer timer;
@@ -1115,6 +1127,7 @@ int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, 
 try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     FlipArgs a{};
     a.source = SRC_BSC;
     a.seed = seed;
@@ -1139,6 +1152,7 @@ int ldpc_flip_mc_run_noalloc(ldpc_flip_decoder *dec, double probability, uint64_
 try {
     if (!dec || !d_counters_out) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     std::lock_guard<std::mutex> lock(dec->mu);
     {
         std::lock_guard<std::mutex> code_lock(dec->code.mu);
@@ -1322,6 +1336,7 @@ int ldpc_bp_mc_run(ldpc_bp_decoder *dec, double noise_probability, uint64_t seed
 try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     BpRun r;
     r.source = SRC_BSC;
     r.test = TEST_RESIDUAL;
@@ -1612,6 +1627,7 @@ int ldpc_css_bp_mc_run(ldpc_css_bp_decoder *dec, double noise_probability, uint6
 try {
     if (!dec || !counters) return fail(LDPC_ERR_BAD_ARG, "null argument");
     if (!valid_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, "probability is not between 0 and 1");
+    if (!samplable_probability(noise_probability)) return fail(LDPC_ERR_BAD_ARG, SAMPLED_PROBABILITY_MSG);
     std::lock_guard<std::mutex> lock(dec->mu);
     for (int i = 0; i < LDPC_COUNTERS; i++) counters[i] = 0;
     GapTable gap = make_gap_table(noise_probability);

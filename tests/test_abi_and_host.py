@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import ldpc_amd
-from ldpc_amd import CssCode, LinearCode
+from ldpc_amd import CssCode, FlipDecoder, LinearCode
 from oracle import oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -167,3 +167,28 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(ldpc_amd.LdpcError) as e:
         code.syndrome_of([0, 2, 4])
     assert e.value.status == ldpc_amd.ERR_HIP
+
+
+def test_probabilities_the_samplers_cannot_represent_are_refused():
+    """noise/mod.rs:35-46 accepts any p in [0, 1] and rand's Bernoulli compares 64 bits; the device samplers hold
+    P(gap >= j) in 32 bits, so 0 < p < 1e-7 would be sampled at a visibly different rate: refused with
+    LDPC_ERR_BAD_ARG before anything is launched.  A decoder PRIOR below that stays legal (it is not sampled)."""
+    import ctypes as C
+    L = ldpc_amd.lib()
+    code = LinearCode.hamming_code()
+    dec = FlipDecoder(code)
+    cnt = (C.c_uint64 * 8)()
+    for p in (1e-9, 9.9e-8, 2.0 ** -40):
+        assert L.ldpc_flip_mc_run(dec._h, p, 1, 0, 4, cnt, None, None, None) == ldpc_amd.ERR_BAD_ARG
+        assert b"1e-7" in L.ldpc_last_error()
+        assert L.ldpc_bsc_sample_batch(p, 64, 1, 0, 1, None) == ldpc_amd.ERR_BAD_ARG
+    from ldpc_amd import BpDecoder
+    BpDecoder(code, 1e-12, 5)      # prior only: accepted
+
+
+def test_code_create_rejects_a_missing_column_array():
+    import ctypes as C
+    L = ldpc_amd.lib()
+    ptr = (C.c_size_t * 2)(0, 2)
+    out = C.c_void_p()
+    assert L.ldpc_code_create(4, 1, ptr, None, C.byref(out)) == ldpc_amd.ERR_BAD_ARG

@@ -98,3 +98,17 @@ def test_erasure_channel_is_the_bernoulli_stream():
             assert e == BinarySymmetricChannel(p).sample_error_of_length(n, 9, shot)
             assert e == sorted(set(e)) and all(0 <= x < n for x in e)
     assert str(ErasureChannel(0.25)) == "Erasure(0.25)"
+
+
+def test_small_probability_rate():
+    """the gap table quantises to 32 bits; at the smallest probabilities it accepts the sampled rate must
+    still be the channel's (mean weight over many shots within 4 sigma), and below 1e-7 the call is refused."""
+    import torch
+    n, shots = 10000, 1 << 17
+    for p in (2e-5, 1e-6, 1.2e-7):
+        d = dev_u64((shots, nwords(n)))
+        BinarySymmetricChannel(p).sample_batch(n, 99, 0, shots, d)
+        w = d.view(torch.uint8).cpu().numpy()
+        weight = int(np.unpackbits(w).sum())
+        mean = n * shots * p
+        assert abs(weight - mean) <= 4 * mean ** 0.5 + 1, (p, weight, mean)
