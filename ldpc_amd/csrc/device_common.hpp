@@ -92,23 +92,31 @@ __device__ inline uint32_t gap_of(const uint32_t *q, float inv_log2q, uint32_t u
     return j;
 }
 
-// One 64-bit word of a BSC sample (binary_symmetric_channel.rs:35-43 distribution).
+// One 64-bit word of a BSC sample (binary_symmetric_channel.rs:35-43 distribution).  The draws of a Philox block are
+// consumed in order x, y, z, w exactly as the sequential definition (DESIGN.md "Noise specification") says; the four
+// gaps of a block are looked up side by side first (independent table searches overlap), then the positions follow in
+// a short chain of adds.  Draws of the last block that the word does not need are discarded, as before.
 __device__ inline uint64_t bsc_word(const uint32_t *q, float inv_log2q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,
                                     uint32_t nbits)
 {
     if (p_is_zero) return 0;
-    DrawStream s;
-    s.init(seed, shot, w);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), s_lo = (uint32_t)shot, s_hi = (uint32_t)(shot >> 32);
     uint64_t word = 0;
     uint32_t pos = 0;
-    for (;;) {
-        pos += gap_of(q, inv_log2q, s.draw());
-        if (pos >= nbits) break;
-        word |= 1ull << pos;
-        pos++;
-        if (pos >= nbits) break;
+    for (uint32_t block = 0;; block++) {
+        uint32_t u[4], g[4];
+        philox4x32_10(s_lo, s_hi, w, block, k0, k1, u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = gap_of(q, inv_log2q, u[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            pos += g[k];
+            if (pos >= nbits) return word;
+            word |= 1ull << pos;
+            pos++;
+            if (pos >= nbits) return word;
+        }
     }
-    return word;
 }
 
 // One word of a depolarizing sample (depolarizing.rs:34-48): x part = X or Y,

@@ -2593,7 +2593,8 @@ hipError_t launch_flip(const DeviceGraph &g, const FlipArgs &a, hipStream_t st)
 }
 
 // waves (= shots in flight) of a flip_big_kernel launch, and the scratch they index
-uint32_t flip_big_waves(uint64_t n_shots) { return (uint32_t)std::min<uint64_t>(n_shots, (uint64_t)device_cu_count() * 8); }
+// (bound by L2 round trips: the more shots in flight the better; 16 waves per CU = 4096 slices of 312 KB at C5)
+uint32_t flip_big_waves(uint64_t n_shots) { return (uint32_t)std::min<uint64_t>(n_shots, (uint64_t)device_cu_count() * 16); }
 size_t flip_big_scratch_bytes(const DeviceGraph &g, uint64_t n_shots)
 {
     return ((size_t)flip_big_waves(n_shots) + 3) / 4 * 4 * flip_big_words(g.n, g.m) * 8;

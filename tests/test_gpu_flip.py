@@ -104,6 +104,24 @@ def test_flip_large_runs_take_the_service_wave_form_and_change_nothing(monkeypat
         assert (ge[i] == e).all() and (gs[i] == oc.syndrome_words(e)).all() and (go[i] == o).all()
 
 
+def test_flip_decode_batch_large_goes_through_the_service_wave_form():
+    """decode_batch (caller's words in, flip counts out) on 70,000 words takes flip4_kernel like a large Monte-Carlo
+    run: decoding the errors a run recorded reproduces its decoded words, syndromes and the flip total."""
+    n, m, shots, p = 10000, 5000, 70000, 0.02
+    code = LinearCode.random_regular_code(n, m, 3, 6, seed=1)
+    dec = FlipDecoder(code)
+    de, ds, do = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u64((shots, nwords(n)))
+    cnt = dec.mc_run(p, SEED, 5, shots, de, ds, do)
+    do2, ds2, df = dev_u64((shots, nwords(n))), dev_u64((shots, nwords(m))), dev_u32((shots,))
+    dec.decode_batch(shots, de, do2, ds2, df)
+    assert bool((do2 == do).all()) and bool((ds2 == ds).all())
+    assert int(df.sum()) == cnt[CNT_WORK]
+    oc = oracle_code(code)
+    gf, ge = host_u32(df), host_u64(de)
+    for i in (0, 1, 34567, shots - 1):
+        assert gf[i] == oc.flip_decode_words(ge[i])[2]
+
+
 def test_flip_irregular_and_ragged():
     rng = np.random.default_rng(3)
     shapes = [(1, 0), (1, 1), (63, 10), (64, 64), (65, 33), (129, 200), (300, 7)]
