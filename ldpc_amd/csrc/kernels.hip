@@ -884,13 +884,21 @@ __device__ inline uint32_t half_row_or_u32(uint32_t v)
     return v;
 }
 
+// bit (pos & 31) of w in one instruction (v_bfe_u32 takes the low five bits of its offset operand by itself; written
+// in C the compiler spends a second instruction on the `& 31` or on the `& 1`)
+__device__ inline uint32_t bit_of(uint32_t w, uint32_t pos)
+{
+    uint32_t d;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(d) : "v"(w), "v"(pos));
+    return d;
+}
+
 // unsatisfied checks of a record >= 2 (bit degree 3: flip.rs:41 `> deg / 2`)
 __device__ inline bool rec3_flippable(const uint4 &r, const char *S)
 {
     const uint32_t w0 = *(const uint32_t *)(S + (r.y >> 16)), w1 = *(const uint32_t *)(S + (r.z >> 16)),
                    w2 = *(const uint32_t *)(S + (r.w >> 16));
-    const uint32_t u = ((w0 >> (r.y & 31)) & 1u) + ((w1 >> (r.z & 31)) & 1u) + ((w2 >> (r.w & 31)) & 1u);
-    return u >= 2;
+    return bit_of(w0, r.y) + bit_of(w1, r.z) + bit_of(w2, r.w) >= 2;
 }
 
 __host__ __device__ constexpr uint32_t flip3_hdr_words(uint32_t list_cap) { return 33 + list_cap / 4 + 1; }
@@ -957,16 +965,20 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         wave_order();
         if (stamp) ts2 = __builtin_amdgcn_s_memtime();
         // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
-        // slot reads the spare check and is never flippable
+        // slot reads the spare check and is never flippable.  Lane = slot (lane & 15) of the errors lane / 16 + 4 u:
+        // the list is padded with the spare row to a multiple of 32 entries, so no lane needs a bounds test, the list
+        // reads differ by constant offsets and a row address is one shift-or on a 32-bit offset.
         constexpr uint32_t P2 = 8;
-        const uint32_t slots = total << 4;
-        for (uint32_t t0i = lane; t0i < slots; t0i += 64 * P2) {
+        const uint32_t padded = (total + 4 * P2 - 1) & ~(4 * P2 - 1);   // <= LIST_CAP (a multiple of 64)
+        if (total + lane < padded) list[total + lane] = (uint16_t)dummy_row;
+        wave_order();
+        const char *nb_base = (const char *)nb;
+        const uint32_t sl16 = (lane & 15) << 4;
+        const uint16_t *lp = list + (lane >> 4);
+        for (uint32_t e0 = 0; e0 < padded; e0 += 4 * P2) {
             uint4 r[P2];
 #pragma unroll
-            for (uint32_t u = 0; u < P2; u++) {
-                const uint32_t t = t0i + 64 * u;
-                r[u] = nb[((size_t)(t < slots ? list[t >> 4] : dummy_row) << 4) + (t & 15)];
-            }
+            for (uint32_t u = 0; u < P2; u++) r[u] = *(const uint4 *)(nb_base + (((uint32_t)lp[e0 + 4 * u] << 8) | sl16));
 #pragma unroll
             for (uint32_t u = 0; u < P2; u++)
                 if (rec3_flippable(r[u], Sc)) {
@@ -1142,8 +1154,8 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
         const uint4 &r = s ? r1 : r0;
         const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16)),
                        wc = *(const uint32_t *)(Sg + (r.w >> 16));
-        const uint32_t conn = (wc >> (r.w & 31)) & 1u;
-        const uint32_t cnt = ((wa >> (r.y & 31)) & 1u) + ((wb >> (r.z & 31)) & 1u) + conn;
+        const uint32_t conn = bit_of(wc, r.w);
+        const uint32_t cnt = bit_of(wa, r.y) + bit_of(wb, r.z) + conn;
         const bool fl = cnt >= 2;                              // flip.rs:41 for three checks
         // One of a neighbour's checks (word 3 of its record) changed by this flip, so its mask bit changes only if
         // the count now sits at the threshold on the side it came from: cnt == 1 + conn, i.e. the other two checks
@@ -1168,6 +1180,68 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
         const unsigned long long t4 = __builtin_amdgcn_s_memtime();
         stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3;
     }
+}
+
+// reductions over each row of 16 lanes (DPP row rotations, every source lane in range)
+__device__ inline uint32_t row_add_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);   // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, true);   // row_ror:2
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);   // row_ror:1
+    return v;
+}
+
+__device__ inline uint32_t row_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, true);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);
+    return v;
+}
+
+// flip3_step with SIXTEEN lanes per shot (four shots per wave), one slot of the row per lane: the same pass with half
+// the work per lane in its longest stretch (the re-evaluation), for launches that keep twice the waves per CU.
+__device__ inline void flip3_step16(const char *nb_base, uint32_t dummy_row, char *Sg, char *Fg, char *log_base, uint32_t log_off,
+                                    uint32_t gl, uint32_t &fs2, uint32_t &nfl)
+{
+    const uint32_t Fg_addr = lds_addr_of(Fg);
+    const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
+    const uint32_t x = *(const uint32_t *)(Fg + (w2 << 6) + gl * 4);
+    uint32_t c;
+    asm("v_ffbl_b32 %0, %1" : "=v"(c) : "v"(x));
+    c |= gl << 5;
+    const uint32_t mpos = row_min_u32(c);
+    const bool found = fs2 != 0 && mpos != NONE;
+    const uint32_t inwin = row_add_u32((uint32_t)__builtin_popcount(x));
+    if (inwin <= 1) fs2 &= fs2 - 1;                             // empty window, or b its only bit: retire it
+    const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
+    const uint4 r = *(const uint4 *)(nb_base + ((b << 8) + gl * 16u));
+    const uint32_t one = found ? 1u : 0u;
+    if (gl == 0) {                                              // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
+        atomicXor((uint32_t *)(Sg + (r.y >> 16)), one << (r.y & 31));
+        atomicXor((uint32_t *)(Sg + (r.z >> 16)), one << (r.z & 31));
+        atomicXor((uint32_t *)(Sg + (r.w >> 16)), one << (r.w & 31));
+        *(uint16_t *)(log_base + (log_off + nfl * 2u)) = (uint16_t)b;   // flip.rs:30, deferred
+    }
+    wave_order();
+    uint32_t contrib = 0;
+    {
+        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16)),
+                       wc = *(const uint32_t *)(Sg + (r.w >> 16));
+        const uint32_t conn = bit_of(wc, r.w);
+        const uint32_t cnt = bit_of(wa, r.y) + bit_of(wb, r.z) + conn;
+        const bool fl = cnt >= 2;                               // flip.rs:41 for three checks
+        if ((r.x & 0x100u) || cnt == 1u + conn) {               // (see flip3_step)
+            const uint32_t m = one << (r.x & 31);
+            lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
+            if (fl) contrib = 1u << (r.x >> 22);
+        }
+    }
+    fs2 |= row_or_u32(contrib);
+    nfl += one;
+    wave_order();
 }
 
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
@@ -1290,12 +1364,15 @@ __host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32
     return 34 + (uint32_t)(sizeof(Flip4Ctl) / 8) + helpers * (list_cap / 4);
 }
 
-template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
+// G = lanes per shot in the flip waves (8: two slots per lane, flip3_step; 16: one slot per lane, flip3_step16),
+// NF + NH = waves of the workgroup (16 for G = 8, one workgroup per CU; 13 for G = 16, two per CU).
+template <int NF, bool PROF = false, int G = 8, int NH = 16 - NF>
+__global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
 {
     extern __shared__ uint64_t lds[];
-    constexpr uint32_t NH = 16 - NF;
+    constexpr uint32_t GPW = 64 / G;   // shots per flip wave
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t grp = lane >> 3, gl = lane & 7;
+    const uint32_t grp = lane / G, gl = lane % G;
     const uint32_t Wn = (g.n + 63) / 64;
     const uint32_t Sw = nbt.sw, per_shot = Sw + nbt.windows * 8;
     const uint32_t LIST_CAP = a.list_cap;
@@ -1457,13 +1534,13 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
             bool took = false;
             if (r0 | r1) {
                 // group k of the needy ones (in lane order) tries the k-th ready slot
-                const uint32_t rank = (uint32_t)__builtin_popcountll(needm & ((1ull << (grp * 8)) - 1));
+                const uint32_t rank = (uint32_t)__builtin_popcountll(needm & ((1ull << (grp * G)) - 1));
                 uint32_t cand = NONE;
                 {
                     uint64_t x0 = r0, x1 = r1;
                     uint32_t k = rank;
-                    // k-th set bit of (r1:r0); at most 8 steps
-                    for (uint32_t s = 0; s < 8; s++) {
+                    // k-th set bit of (r1:r0); at most GPW steps
+                    for (uint32_t s = 0; s < GPW; s++) {
                         if (s == k) cand = x0 ? (uint32_t)__builtin_ctzll(x0) : x1 ? 64u + (uint32_t)__builtin_ctzll(x1) : NONE;
                         if (x0) x0 &= x0 - 1;
                         else x1 &= x1 - 1;
@@ -1475,8 +1552,8 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
                     ok = __hip_atomic_compare_exchange_strong(&ctl->status[cand], &expect, F4_RUNNING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
                 }
-                ok = __shfl(ok, grp * 8, 64);   // the group's lane 0 made the attempt
-                cand = __shfl(cand, grp * 8, 64);
+                ok = __shfl(ok, grp * G, 64);   // the group's lane 0 made the attempt
+                cand = __shfl(cand, grp * G, 64);
                 if (slot == NONE && ok) {
                     slot = cand;
                     took = true;
@@ -1505,7 +1582,8 @@ template <int NF, bool PROF = false> __global__ __launch_bounds__(1024) void fli
             }
             idle = 0;
         }
-        flip3_step<PROF>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
+        if (G == 16) flip3_step16((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl);
+        else flip3_step<PROF>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
         if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
             if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
@@ -2815,7 +2893,7 @@ uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf)
     return (uint32_t)std::min<size_t>(F4_MAX_SLOTS, (room - hdr) / per);
 }
 
-uint32_t flip4_scratch_pieces() { return device_cu_count() * F4_LOGS; }
+uint32_t flip4_scratch_pieces() { return 2 * device_cu_count() * F4_LOGS; }   // (up to two workgroups per CU)
 
 typedef void (*flip4_fn)(DeviceGraph, Nb3Table, FlipArgs, uint32_t);
 static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
@@ -2831,10 +2909,50 @@ static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
     }
 }
 
+// flip4 with 16 lanes per shot: two workgroups per CU of NF flip waves (4 shots each) + NH service waves
+struct Flip4Wide {
+    flip4_fn fn;
+    uint32_t nf, nh;
+    const char *name;
+};
+static Flip4Wide flip4_wide_for(int sel)
+{
+    switch (sel) {
+    case 1608: return {flip4_kernel<8, false, 16, 4>, 8, 4, "flip4_kernel<8,16 lanes,4>"};
+    case 1610: return {flip4_kernel<10, false, 16, 4>, 10, 4, "flip4_kernel<10,16 lanes,4>"};
+    case 1611: return {flip4_kernel<11, false, 16, 4>, 11, 4, "flip4_kernel<11,16 lanes,4>"};
+    case 1612: return {flip4_kernel<12, false, 16, 4>, 12, 4, "flip4_kernel<12,16 lanes,4>"};
+    case 1609: default: return {flip4_kernel<9, false, 16, 4>, 9, 4, "flip4_kernel<9,16 lanes,4>"};
+    }
+}
+
+// slots of a 16-lane workgroup: half of a CU's LDS
+static uint32_t flip4_wide_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nh)
+{
+    const size_t hdr = (size_t)flip4_hdr_words(list_cap, nh) * 8, per = ((size_t)t.sw + (size_t)t.windows * 8) * 8;
+    const size_t room = 80 * 1024 - 1024;
+    if (hdr + per > room) return 0;
+    return (uint32_t)std::min<size_t>(F4_MAX_SLOTS, (room - hdr) / per);
+}
+
 hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
     if (a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
+    if (switches().flip_nf >= 1600) {
+        // (A/B: LDPC_HIP_FLIP_NF = 16xx selects the 16-lane form with xx flip waves per workgroup)
+        const Flip4Wide w = flip4_wide_for(switches().flip_nf);
+        const uint32_t n_slots = flip4_wide_slots(nb, a.list_cap, w.nh);
+        if (n_slots < w.nf * 4 + 1) return hipErrorInvalidValue;
+        const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, w.nh) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * device_cu_count(), (a.n_shots + 63) / 64);
+        hipError_t e = hipFuncSetAttribute((const void *)w.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (switches().debug) std::fprintf(stderr, "[ldpc_hip] %s: %u slots, lds %zu B, grid %u\n", w.name, n_slots, lds, grid);
+        g_kernel_name = w.name;
+        hipLaunchKernelGGL(w.fn, dim3(grid), dim3((w.nf + w.nh) * 64), lds, st, g, nb, a, n_slots);
+        return hipGetLastError();
+    }
     // flip waves of the 16: measured at C2 8 -> 7.2e7, 9 -> 7.6e7 shots/s, 10 -> the service waves do not keep up
     // (LDPC_HIP_FLIP_NF: A/B aid); fewer when the LDS holds fewer slots than their groups plus one per service wave
     uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 9u;
