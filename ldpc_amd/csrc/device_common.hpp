@@ -119,6 +119,37 @@ __device__ inline uint64_t bsc_word(const uint32_t *q, float inv_log2q, bool p_i
     }
 }
 
+// One Philox block of a word's BSC stream, for callers that keep (word, pos) themselves: the same draws, gaps and
+// positions as bsc_word's loop body, with the usual case of a gap look-up (the float estimate is the answer: q[j] > u
+// >= q[j + 1]) checked for the four draws together and without branches.  `q` must hold q[65] = 0 after the table.
+// Returns true when the word is complete.
+__device__ inline bool bsc_block(const uint32_t *q, float inv_log2q, uint32_t k0, uint32_t k1, uint32_t s_lo, uint32_t s_hi, uint32_t w,
+                                 uint32_t block, uint32_t nbits, uint64_t &word, uint32_t &pos)
+{
+    uint32_t u[4], g[4];
+    philox4x32_10(s_lo, s_hi, w, block, k0, k1, u);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float est = (__log2f((float)u[k]) - 32.0f) * inv_log2q;
+        const uint32_t j = (uint32_t)fminf(fmaxf(est, 0.0f), 64.0f);
+        const uint32_t a = q[j], b = q[j + 1];
+        bad |= (u[k] < b) | (j > 0 && !(u[k] < a));
+        g[k] = j;
+    }
+    if (bad) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) g[k] = gap_of(q, inv_log2q, u[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        pos += g[k];
+        word |= pos < nbits ? 1ull << (pos & 63) : 0ull;
+        pos++;
+    }
+    return pos >= nbits;   // (pos only grows: once past the end nothing more is set)
+}
+
 // One word of a depolarizing sample (depolarizing.rs:34-48): x part = X or Y,
 // z part = Z or Y (css.rs:92-99).
 __device__ inline void depol_word(const uint32_t *q, float inv_log2q, bool p_is_zero, uint64_t seed, uint64_t shot, uint32_t w,

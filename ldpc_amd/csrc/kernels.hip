@@ -924,23 +924,78 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
     for (uint32_t w = lane; w < per_shot; w += 64) S[w] = 0;
     if (lane == 0) *cnt_lds = 0;
     wave_order();
-    // noise (or the caller's word); error positions go to the LDS list as they appear
-    for (uint32_t w = lane; w < Wn; w += 64) {
-        const uint32_t nb_bits = bits_in_word(g.n, w);
-        uint64_t x;
-        if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb_bits);
-        else {
-            x = a.words_in[i * Wn + w];
-            if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
+    // noise (or the caller's word); error positions go to the LDS list
+    if (a.source == SRC_BSC) {
+        // A lane samples the words lane, lane + 64, ... (at most four: n + 512 <= 16384).  Block 0 of every word
+        // first; the few words that need further Philox blocks (four or more errors in 64 bits: 4 % at p = 0.02)
+        // are then finished together, lowest pending word of each lane per pass, instead of one sparse pass per
+        // round of words.  The stream of a word is the sequential one (DESIGN.md "Noise specification").
+        const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), s_lo = (uint32_t)shot, s_hi = (uint32_t)(shot >> 32);
+        const uint32_t rounds = (Wn + 63) / 64;
+        uint64_t xs[4] = {0, 0, 0, 0};
+        uint32_t ps[4] = {0, 0, 0, 0}, pend = 0;
+        if (!a.gap.p_is_zero) {
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++)
+                if (r < rounds) {
+                    const uint32_t w = lane + 64 * r;
+                    if (w < Wn && !bsc_block(q, a.gap.inv_log2q, k0, k1, s_lo, s_hi, w, 0, bits_in_word(g.n, w), xs[r], ps[r])) pend |= 1u << r;
+                }
+            uint32_t tb = 1;
+            while (__ballot(pend != 0)) {
+                if (pend) {
+                    const uint32_t r = (uint32_t)__builtin_ctz(pend);
+                    uint64_t x = r == 0 ? xs[0] : (r == 1 ? xs[1] : (r == 2 ? xs[2] : xs[3]));
+                    uint32_t pp = r == 0 ? ps[0] : (r == 1 ? ps[1] : (r == 2 ? ps[2] : ps[3]));
+                    const uint32_t w = lane + 64 * r;
+                    const bool done = bsc_block(q, a.gap.inv_log2q, k0, k1, s_lo, s_hi, w, tb, bits_in_word(g.n, w), x, pp);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++)
+                        if (r == u) {
+                            xs[u] = x;
+                            ps[u] = pp;
+                        }
+                    if (done) {
+                        pend &= pend - 1;
+                        tb = 1;
+                    } else tb++;
+                }
+            }
         }
-        O[w] = x;
-        const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+        uint32_t cc = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++)
+            if (r < rounds) {
+                const uint32_t w = lane + 64 * r;
+                if (w < Wn) O[w] = xs[r];
+                cc += (uint32_t)__builtin_popcountll(xs[r]);
+            }
         if (cc) {
             uint32_t off = atomicAdd(cnt_lds, cc);
-            while (x) {
-                if (off < LIST_CAP) list[off] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
-                off++;
-                x &= x - 1;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                uint64_t x = xs[r];
+                while (x) {
+                    if (off < LIST_CAP) list[off] = (uint16_t)(((lane + 64 * r) << 6) + (uint32_t)__builtin_ctzll(x));
+                    off++;
+                    x &= x - 1;
+                }
+            }
+        }
+    } else {
+        for (uint32_t w = lane; w < Wn; w += 64) {
+            const uint32_t nb_bits = bits_in_word(g.n, w);
+            uint64_t x = a.words_in[i * Wn + w];
+            if (nb_bits < 64) x &= (1ull << nb_bits) - 1;
+            O[w] = x;
+            const uint32_t cc = (uint32_t)__builtin_popcountll(x);
+            if (cc) {
+                uint32_t off = atomicAdd(cnt_lds, cc);
+                while (x) {
+                    if (off < LIST_CAP) list[off] = (uint16_t)((w << 6) + (uint32_t)__builtin_ctzll(x));
+                    off++;
+                    x &= x - 1;
+                }
             }
         }
     }
@@ -1258,7 +1313,7 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
     uint32_t *cnt_lds = (uint32_t *)(lds + 33 + LIST_CAP / 4);
     uint64_t *state = lds + flip3_hdr_words(LIST_CAP);
 
-    for (uint32_t i = lane; i < 65; i += 64) q[i] = a.gap.q[i];
+    for (uint32_t i = lane; i < 66; i += 64) q[i] = i < 65 ? a.gap.q[i] : 0u;   // (q[65] = 0: bsc_block reads one past the table)
     wave_sync();
 
     uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
@@ -1386,7 +1441,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     const uint32_t count = lo >= a.n_shots ? 0u : (uint32_t)(a.n_shots - lo < chunk ? a.n_shots - lo : chunk);
     if (count == 0) return;
 
-    for (uint32_t i = threadIdx.x; i < 65; i += blockDim.x) q[i] = a.gap.q[i];
+    for (uint32_t i = threadIdx.x; i < 66; i += blockDim.x) q[i] = i < 65 ? a.gap.q[i] : 0u;   // (q[65] = 0: bsc_block reads one past the table)
     for (uint32_t i = threadIdx.x; i < sizeof(Flip4Ctl) / 4; i += blockDim.x) ((uint32_t *)ctl)[i] = 0;
     __syncthreads();
 
