@@ -1030,16 +1030,37 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         const char *nb_base = (const char *)nb;
         const uint32_t sl16 = (lane & 15) << 4;
         const uint16_t *lp = list + (lane >> 4);
-        for (uint32_t e0 = 0; e0 < padded; e0 += 4 * P2) {
-            uint4 r[P2];
+        // (two sets of records: the rows of the next 32 errors are on their way while this set is evaluated; a set's
+        // 24 syndrome words are read together, then the slots decide)
+        auto load = [&](uint4(&r)[P2], uint32_t e0) {
 #pragma unroll
             for (uint32_t u = 0; u < P2; u++) r[u] = *(const uint4 *)(nb_base + (((uint32_t)lp[e0 + 4 * u] << 8) | sl16));
+        };
+        auto eval = [&](const uint4(&r)[P2]) {
+            uint32_t wa[P2], wb[P2], wc[P2];
+#pragma unroll
+            for (uint32_t u = 0; u < P2; u++) {
+                wa[u] = *(const uint32_t *)(Sc + (r[u].y >> 16));
+                wb[u] = *(const uint32_t *)(Sc + (r[u].z >> 16));
+                wc[u] = *(const uint32_t *)(Sc + (r[u].w >> 16));
+            }
 #pragma unroll
             for (uint32_t u = 0; u < P2; u++)
-                if (rec3_flippable(r[u], Sc)) {
+                if (bit_of(wa[u], r[u].y) + bit_of(wb[u], r[u].z) + bit_of(wc[u], r[u].w) >= 2) {   // flip.rs:41
                     atomicOr((uint32_t *)(Fc + (r[u].x >> 16)), 1u << (r[u].x & 31));
                     summary |= 1u << (r[u].x >> 22);
                 }
+        };
+        uint4 ra[P2], rb[P2];
+        if (padded) load(ra, 0);
+        for (uint32_t e0 = 0; e0 < padded; e0 += 8 * P2) {
+            const bool second = e0 + 4 * P2 < padded;
+            if (second) load(rb, e0 + 4 * P2);
+            eval(ra);
+            if (second) {
+                if (e0 + 8 * P2 < padded) load(ra, e0 + 8 * P2);
+                eval(rb);
+            }
         }
     } else {
         // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words
@@ -1130,7 +1151,7 @@ __device__ inline uint32_t flip3_output_shot(const DeviceGraph &g, const Nb3Tabl
 // each shot is flipped (flip.rs:27-30), or, when the scanned window of its mask holds none, the window is retired.
 // Sg / Fg: the group's shot state in LDS; fs2: summary of F (0: nothing to do -- the group then works the spare row
 // and changes nothing); nfl: flips so far = position in the flip log.
-template <bool STAMP = false, int VARIANT = 1>
+template <bool STAMP = false, int SV = 0>
 __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char *Sg, char *Fg, char *log_base, uint32_t log_off,
                                   uint32_t gl, uint32_t &fs2, uint32_t &nfl, unsigned long long *stamp = nullptr)
 {
@@ -1182,49 +1203,30 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
     wave_order();
     // Both slots re-evaluate their bit against the new syndrome.  One of a neighbour's checks (word 3 of its record)
     // changed by this flip, so its mask bit changes only if the count now sits at the threshold on the side it came
-    // from (count == 1 + that check); the record's flag covers the bits for which that does not hold.  Few lanes
-    // write, so the mask update costs the LDS little.
+    // from: count == 1 + that check, i.e. the other two checks hold exactly one unsatisfied; the record's flag covers
+    // the slots for which that does not hold (b itself, doubly connected bits).  Few lanes write, so the mask update
+    // costs the LDS little.
+    // All six syndrome words are read before either slot decides: one LDS round trip on the pass's dependent chain
+    // instead of two (+6 % at C2 under flip4_kernel).  Other forms of this stretch measured there: every lane
+    // rewriting its bit, or writing under an empty mask instead of branching (-0.5 %); the third word read only by the
+    // lanes that write (no difference); the three toggles spread over three lanes' records so that one LDS
+    // instruction carries them (-1.7 %, although it saves nine instructions).  (SV: spare switch for such A/B forms,
+    // LDPC_HIP_FLIP_NF = 100 * SV + flip waves.)
     uint32_t contrib = 0;
-    if (VARIANT == 0) {
-        // every slot reads its three checks and rewrites its mask bit (no branch, eight LDS operations per lane)
-        const bool f0 = rec3_flippable(r0, Sg), f1 = rec3_flippable(r1, Sg);
-        const uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
-        lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
-        lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
-        contrib = (f0 ? 1u << (r0.x >> 22) : 0u) | (f1 ? 1u << (r1.x >> 22) : 0u);
-    } else if (VARIANT == 2) {
-        const uint32_t wa0 = *(const uint32_t *)(Sg + (r0.y >> 16)), wb0 = *(const uint32_t *)(Sg + (r0.z >> 16)),
-                       wc0 = *(const uint32_t *)(Sg + (r0.w >> 16)), wa1 = *(const uint32_t *)(Sg + (r1.y >> 16)),
-                       wb1 = *(const uint32_t *)(Sg + (r1.z >> 16)), wc1 = *(const uint32_t *)(Sg + (r1.w >> 16));
-        const uint32_t s0 = ((wa0 >> (r0.y & 31)) & 1u) + ((wb0 >> (r0.z & 31)) & 1u), s1 = ((wa1 >> (r1.y & 31)) & 1u) + ((wb1 >> (r1.z & 31)) & 1u);
-        const bool f0 = s0 + ((wc0 >> (r0.w & 31)) & 1u) >= 2, f1 = s1 + ((wc1 >> (r1.w & 31)) & 1u) >= 2;
-        // unchanged slots write with an empty mask: no branch, the LDS still sees every lane
-        const uint32_t m0 = ((r0.x & 0x100u) || s0 == 1u) ? one << (r0.x & 31) : 0u, m1 = ((r1.x & 0x100u) || s1 == 1u) ? one << (r1.x & 31) : 0u;
-        lds_mskor(Fg_addr + (r0.x >> 16), m0, f0 ? m0 : 0u);
-        lds_mskor(Fg_addr + (r1.x >> 16), m1, f1 ? m1 : 0u);
-        contrib = (f0 && m0 ? 1u << (r0.x >> 22) : 0u) | (f1 && m1 ? 1u << (r1.x >> 22) : 0u);
-    } else {
+    uint32_t w6[6];
+    w6[0] = *(const uint32_t *)(Sg + (r0.y >> 16)); w6[1] = *(const uint32_t *)(Sg + (r0.z >> 16)); w6[2] = *(const uint32_t *)(Sg + (r0.w >> 16));
+    w6[3] = *(const uint32_t *)(Sg + (r1.y >> 16)); w6[4] = *(const uint32_t *)(Sg + (r1.z >> 16)); w6[5] = *(const uint32_t *)(Sg + (r1.w >> 16));
+    asm volatile("" : "+v"(w6[0]), "+v"(w6[1]), "+v"(w6[2]), "+v"(w6[3]), "+v"(w6[4]), "+v"(w6[5]));
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const uint4 &r = s ? r1 : r0;
-        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16)),
-                       wc = *(const uint32_t *)(Sg + (r.w >> 16));
-        const uint32_t conn = bit_of(wc, r.w);
-        const uint32_t cnt = bit_of(wa, r.y) + bit_of(wb, r.z) + conn;
-        const bool fl = cnt >= 2;                              // flip.rs:41 for three checks
-        // One of a neighbour's checks (word 3 of its record) changed by this flip, so its mask bit changes only if
-        // the count now sits at the threshold on the side it came from: cnt == 1 + conn, i.e. the other two checks
-        // hold exactly one unsatisfied (the compiler tests that and reads the third word only in the lanes that
-        // write); the record's flag covers the slots for which it does not hold (b itself, doubly connected bits).
-        // Measured at C2 under flip4_kernel against other schedules of the same work -- all six reads up front
-        // (6.6e7 shots/s), both slots' first two reads together and then the third reads (7.3e7), every lane
-        // rewriting its bit (VARIANT 0, 7.2e7): this slot-after-slot form is the fastest (7.8e7).
-        if ((r.x & 0x100u) || cnt == 1u + conn) {
+        const uint32_t ab = bit_of(w6[3 * s], r.y) + bit_of(w6[3 * s + 1], r.z);
+        if ((r.x & 0x100u) || ab == 1u) {
+            const bool fl = ab + bit_of(w6[3 * s + 2], r.w) >= 2;   // flip.rs:41 for three checks
             const uint32_t m = one << (r.x & 31);
             lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
             if (fl) contrib |= 1u << (r.x >> 22);
         }
-    }
     }
     fs2 |= half_row_or_u32(contrib);
     nfl += one;
@@ -1283,12 +1285,11 @@ __device__ inline void flip3_step16(const char *nb_base, uint32_t dummy_row, cha
     wave_order();
     uint32_t contrib = 0;
     {
-        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16)),
-                       wc = *(const uint32_t *)(Sg + (r.w >> 16));
-        const uint32_t conn = bit_of(wc, r.w);
-        const uint32_t cnt = bit_of(wa, r.y) + bit_of(wb, r.z) + conn;
-        const bool fl = cnt >= 2;                               // flip.rs:41 for three checks
-        if ((r.x & 0x100u) || cnt == 1u + conn) {               // (see flip3_step)
+        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16));
+        const uint32_t ab = bit_of(wa, r.y) + bit_of(wb, r.z);
+        if ((r.x & 0x100u) || ab == 1u) {                       // (see flip3_step)
+            const uint32_t wc = *(const uint32_t *)(Sg + (r.w >> 16));
+            const bool fl = ab + bit_of(wc, r.w) >= 2;          // flip.rs:41 for three checks
             const uint32_t m = one << (r.x & 31);
             lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
             if (fl) contrib = 1u << (r.x >> 22);
@@ -1421,7 +1422,7 @@ __host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32
 
 // G = lanes per shot in the flip waves (8: two slots per lane, flip3_step; 16: one slot per lane, flip3_step16),
 // NF + NH = waves of the workgroup (16 for G = 8, one workgroup per CU; 13 for G = 16, two per CU).
-template <int NF, bool PROF = false, int G = 8, int NH = 16 - NF>
+template <int NF, bool PROF = false, int G = 8, int NH = 16 - NF, int SV = 0>
 __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
 {
     extern __shared__ uint64_t lds[];
@@ -1638,7 +1639,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
             idle = 0;
         }
         if (G == 16) flip3_step16((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl);
-        else flip3_step<PROF>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
+        else flip3_step<PROF, SV>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
         if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
             if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
@@ -2960,6 +2961,7 @@ static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
     case 8: return prof ? flip4_kernel<8, true> : flip4_kernel<8>;
     case 9: return prof ? flip4_kernel<9, true> : flip4_kernel<9>;
     case 10: return flip4_kernel<10>;
+    case 109: return flip4_kernel<9, false, 8, 7, 1>;
     default: return nullptr;
     }
 }
@@ -3012,7 +3014,8 @@ hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
     // (LDPC_HIP_FLIP_NF: A/B aid); fewer when the LDS holds fewer slots than their groups plus one per service wave
     uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 9u;
     while (nf > 4 && (!flip4_kernel_for(nf, false) || flip4_slots(nb, a.list_cap, nf) < nf * 8 + (16 - nf))) nf--;
-    const flip4_fn k = flip4_kernel_for(nf, switches().flip_prof);
+    flip4_fn k = flip4_kernel_for(nf, switches().flip_prof);
+    if (nf == 9 && switches().flip_nf > 100 && flip4_kernel_for(switches().flip_nf, false)) k = flip4_kernel_for(switches().flip_nf, false);
     const uint32_t n_slots = flip4_slots(nb, a.list_cap, nf);
     if (!k || n_slots < nf * 8 + 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, 16 - nf) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;
