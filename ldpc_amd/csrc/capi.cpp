@@ -595,6 +595,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.ssl = (uint64_t *)base;
     base += groups * (size_t)g.m * 8;
     a.esl = (uint64_t *)base;
+    base += groups * (size_t)g.n * 8;
+    a.psl = (uint64_t *)base;
     a.gap = r.gap;
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);

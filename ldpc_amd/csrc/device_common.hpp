@@ -134,7 +134,8 @@ __device__ inline bool bsc_block(const uint32_t *q, float inv_log2q, uint32_t k0
         const float est = (__log2f((float)u[k]) - 32.0f) * inv_log2q;
         const uint32_t j = (uint32_t)fminf(fmaxf(est, 0.0f), 64.0f);
         const uint32_t a = q[j], b = q[j + 1];
-        bad |= (u[k] < b) | (j > 0 && !(u[k] < a));
+        // (q[0] = 2^32 - 1 stands for 2^32: the one draw it misjudges, u = 2^32 - 1 at j = 0, only takes the exact path)
+        bad |= (u[k] < b) | !(u[k] < a);
         g[k] = j;
     }
     if (bad) {

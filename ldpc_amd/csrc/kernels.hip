@@ -1740,7 +1740,7 @@ template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uin
 template <int DV>
 __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32_t split, uint32_t lane, bool active,
                                      uint64_t actmask, double prior, const double *chkm, double *bitsm, uint64_t *dw,
-                                     uint64_t *dsl)
+                                     uint64_t *dsl, uint64_t *psl = nullptr)
 {
     // item = chunk * split + piece: a 64-bit chunk is worked in `split` (1, 2 or 4) pieces, so that codes with
     // few chunks still spread evenly over the waves of a group
@@ -1903,7 +1903,15 @@ __device__ inline void bp_bits_chunk(const DeviceGraph &g, uint32_t item, uint32
         else ((uint16_t *)dw)[((size_t)chunk * 64 + lane) * 4 + piece] = (uint16_t)dacc;
     }
     const uint32_t bb = b0 + lane;
-    if (bb < b1) dsl[bb] = (dsl[bb] & ~actmask) | slice;
+    if (bb < b1) {
+        const uint64_t old = dsl[bb];
+        dsl[bb] = (old & ~actmask) | slice;
+        // streamed form: the stop test's residual syndrome ^ H * decision follows the decisions that changed (few after
+        // the first iterations), instead of being gathered anew from every bit's row in every iteration
+        const uint64_t chg = (old & actmask) ^ slice;
+        if (psl && chg)
+            for (uint32_t k = g.t_ptr[bb]; k < g.t_ptr[bb + 1]; k++) atomicXor((unsigned long long *)&psl[g.t_idx[k]], (unsigned long long)chg);
+    }
 }
 
 // DC / DV > 0: every check has exactly DC bits / every bit exactly DV checks (regular code):
@@ -2244,7 +2252,7 @@ constexpr uint32_t BPS_THREADS = 256, BPS_WAVES = BPS_THREADS / 64;
 
 struct BpsGroup {
     double *bitsm, *chkm;
-    uint64_t *ew, *dw, *dsl, *ssl, *esl;
+    uint64_t *ew, *dw, *dsl, *ssl, *esl, *psl;
 };
 
 __device__ inline BpsGroup bps_group(const DeviceGraph &g, const BpArgs &a, size_t grp)
@@ -2258,6 +2266,7 @@ __device__ inline BpsGroup bps_group(const DeviceGraph &g, const BpArgs &a, size
     r.dsl = a.dsl + grp * (size_t)g.n;
     r.ssl = a.ssl + grp * (size_t)g.m;
     r.esl = a.esl + grp * (size_t)g.n;
+    r.psl = a.psl + grp * (size_t)g.m;
     return r;
 }
 
@@ -2362,7 +2371,11 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_words(DeviceGraph g, Bp
                 if (lane == i) row = mask;
             }
             const uint32_t c = w * 64 + lane;
-            if (c < g.m) G.ssl[c] = (G.ssl[c] & ~takemask) | (row & takemask);
+            if (c < g.m) {
+                G.ssl[c] = (G.ssl[c] & ~takemask) | (row & takemask);
+                const uint64_t ipar = init && ((g.h_ptr[c + 1] - g.h_ptr[c]) & 1u) ? ~0ull : 0ull;   // H * (all-ones decision)
+                G.psl[c] = (G.psl[c] & ~takemask) | ((row ^ ipar) & takemask);
+            }
         }
     }
 }
@@ -2379,6 +2392,23 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_setup_synd(DeviceGraph g, BpA
         uint64_t par = 0;
         for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) par ^= G.esl[g.h_idx[e]];
         G.ssl[c] = (G.ssl[c] & ~takemask) | (par & takemask);
+        // residual of the decision before the first update (bps_setup_words: all ones when the prior is negative)
+        const uint64_t ipar = a.prior < 0.0 && ((g.h_ptr[c + 1] - g.h_ptr[c]) & 1u) ? ~0ull : 0ull;
+        G.psl[c] = (G.psl[c] & ~takemask) | ((par ^ ipar) & takemask);
+    }
+}
+
+// (group, part): residual rows of every check from the decision rows (the persistent kernel's tail arrives without them)
+__global__ __launch_bounds__(BPS_THREADS) void bps_parity_init(DeviceGraph g, BpArgs a, BpsState s, uint32_t parts, uint32_t g0)
+{
+    const size_t grp = bps_grp(s, g0 + blockIdx.x / parts);
+    const uint32_t part = blockIdx.x % parts;
+    if (!s.act[grp]) return;
+    const BpsGroup G = bps_group(g, a, grp);
+    for (uint32_t c = part * BPS_THREADS + threadIdx.x; c < g.m; c += parts * BPS_THREADS) {
+        uint64_t x = G.ssl[c];
+        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= G.dsl[g.h_idx[e]];
+        G.psl[c] = x;
     }
 }
 
@@ -2390,11 +2420,8 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_stop(DeviceGraph g, BpArgs a,
     if (!s.act[grp] || (only_fresh && !s.take[grp])) return;
     const BpsGroup G = bps_group(g, a, grp);
     uint64_t acc = 0;
-    for (uint32_t c = part * BPS_THREADS + threadIdx.x; c < g.m; c += parts * BPS_THREADS) {
-        uint64_t x = G.ssl[c];
-        for (uint32_t e = g.h_ptr[c]; e < g.h_ptr[c + 1]; e++) x ^= G.dsl[g.h_idx[e]];
-        acc |= x;
-    }
+    // (the residual rows are kept up to date by the bit update: one coalesced pass, no gathers)
+    for (uint32_t c = part * BPS_THREADS + threadIdx.x; c < g.m; c += parts * BPS_THREADS) acc |= G.psl[c];
     acc = wave_or64(acc);
     if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long *)&s.mism[grp], (unsigned long long)acc);
 }
@@ -2556,7 +2583,7 @@ __device__ inline void bps_bits_body(const DeviceGraph &g, const BpArgs &a, cons
     const uint32_t Wn = (g.n + 63) / 64;
     // (split: pieces per 64-bit chunk, 1 when the groups in play fill the chip with whole chunks; see bp_stream_run)
     for (uint32_t item = part * BPS_WAVES + wv; item < Wn * split; item += parts * BPS_WAVES)
-        bp_bits_chunk<DV>(g, item, split, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl);
+        bp_bits_chunk<DV>(g, item, split, lane, active, actmask, a.prior, G.chkm, G.bitsm, G.dw, G.dsl, G.psl);
 }
 
 // One half-step of the streamed form: update_checks on the groups [gc0, gc0 + gcn) and update_bits on the
@@ -2647,6 +2674,13 @@ __global__ __launch_bounds__(BPS_THREADS) void bps_compact(DeviceGraph g, BpArgs
             if (lane == i) row = mask;
         }
         if (lane < cnt) D.ssl[c0 + lane] = (D.ssl[c0 + lane] & ~recvmask) | row;
+        row = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const bool bit = recv && ((S.psl[c0 + i] >> sslot) & 1ull);
+            const uint64_t mask = __ballot(bit);
+            if (lane == i) row = mask;
+        }
+        if (lane < cnt) D.psl[c0 + lane] = (D.psl[c0 + lane] & ~recvmask) | row;
     }
     if (part == 0 && wv == 0 && recv) {
         s.iter[dgrp * 64 + lane] = s.iter[mv];
@@ -2670,7 +2704,7 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap)
 size_t bp_workspace_bytes_per_group(const DeviceGraph &g)
 {
     size_t Wn = (g.n + 63) / 64;
-    return 2 * (size_t)g.E * 64 * sizeof(double) + 2 * Wn * 64 * sizeof(uint64_t) + (2 * (size_t)g.n + g.m) * sizeof(uint64_t);
+    return 2 * (size_t)g.E * 64 * sizeof(double) + 2 * Wn * 64 * sizeof(uint64_t) + (2 * (size_t)g.n + 2 * (size_t)g.m) * sizeof(uint64_t);
 }
 
 hipError_t launch_sample_bsc(const GapTable &gap, uint32_t n, uint64_t seed, uint64_t first, uint64_t n_shots,
@@ -3210,6 +3244,7 @@ hipError_t bp_stream_run(const DeviceGraph &g, const BpArgs &a, void *state, uin
         return hipGetLastError();
     };
     const bool may_compact = !skew && !switches().bp_no_compact;   // (A/B and test aid)
+    if (resume) hipLaunchKernelGGL(bps_parity_init, dim3(groups * parts), blk, 0, st, g, a, s, parts, 0u);
     for (int t = 0; t < 2; t++)
         if (setn[t] && (e = control(t)) != hipSuccess) return e;
     if (resume && alive[0]) {

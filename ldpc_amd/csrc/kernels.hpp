@@ -114,6 +114,7 @@ struct BpArgs {
     uint64_t *dw;               // [groups][Wn][64] hard decisions, packed per slot
     uint64_t *dsl;              // [groups][n]      hard decisions, bit-sliced over slots
     uint64_t *ssl;              // [groups][m]      syndromes, bit-sliced over slots
+    uint64_t *psl;              // [groups][m]      streamed form: syndrome ^ H * decision (the stop test's residual), bit-sliced
     uint64_t *esl;              // [groups][n]      error words of the slots being refilled, bit-sliced (set-up scratch)
     GapTable gap;
 };
