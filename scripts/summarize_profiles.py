@@ -28,12 +28,12 @@ def log_line(sub, key):
 
 
 out = {}
-# ---- flip: bench.py --steps 3 --warmup 1 (4 launches of 2^20 shots)
+# ---- flip: bench.py --steps 3 --warmup 1 (4 launches of the bench's default shots per step)
 keep_stats("flip", "flip")
 k = summarize(os.path.join(src, "flip"), "flip4_kernel")
 launches = k["time"]["calls"]
-shots = 1 << 20
 bench = json.loads(log_line("flip", '"metric"'))
+shots = int(bench["config"]["shots_per_gpu_per_step"])
 flip = {
     "command": "scripts/profile_round.sh: rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group, -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bp",
     "kernel": bench["roofline"]["kernel"], "launches": launches, "shots_per_launch": shots,
