@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "bp_math.hpp"
@@ -2040,6 +2042,8 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
         if (!actmask) break;
         lap(0);
 
+        // (The streamed form keeps syndrome ^ H * decision up to date from the bit update instead, bps_stop; tried here
+        // too: at C2 the decision rows are L2-resident, the gathers cheap, and the extra atomics cost 5 %.)
         // ---- stop test (belief_propagation.rs:26-27), bit-sliced over the 64 slots: the threads of
         // the group split the checks, each XORs whole 64-slot words; partial masks are OR-ed in LDS
         if (tid == 0) sh_mism = 0;
@@ -3079,15 +3083,24 @@ static bp_kernel_fn bp_kernel_for(int dc, int dv)
     return bp_kernel<0, 0>;
 }
 
-// workgroups of `waves` wavefronts that are resident at once on the whole device
+// workgroups of `waves` wavefronts that are resident at once on the whole device (asked of the runtime once per
+// device and kernel form: the single-vector calls take 0.1-0.4 ms and should not pay an occupancy query each)
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv)
 {
-    int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bp_kernel_for(dc, dv), (int)(64 * waves), 0) != hipSuccess ||
-        per_cu < 1)
-        per_cu = 1;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return (uint32_t)per_cu * (uint32_t)(cus > 0 ? cus : 256);
+    static std::mutex mu;
+    static std::map<std::tuple<int, uint32_t, const void *>, uint32_t> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *fn = (const void *)bp_kernel_for(dc, dv);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(std::make_tuple(dev, waves, fn));
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)(64 * waves), 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t r = (uint32_t)per_cu * (uint32_t)(cus > 0 ? cus : 256);
+    cache[std::make_tuple(dev, waves, fn)] = r;
+    return r;
 }
 
 hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uint32_t waves, int dc, int dv,
