@@ -1241,67 +1241,6 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
     }
 }
 
-// reductions over each row of 16 lanes (DPP row rotations, every source lane in range)
-__device__ inline uint32_t row_add_u32(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);   // row_ror:4
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, true);   // row_ror:2
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);   // row_ror:1
-    return v;
-}
-
-__device__ inline uint32_t row_or_u32(uint32_t v)
-{
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xF, 0xF, true);
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, true);
-    return v;
-}
-
-// flip3_step with SIXTEEN lanes per shot (four shots per wave), one slot of the row per lane: the same pass with half
-// the work per lane in its longest stretch (the re-evaluation), for launches that keep twice the waves per CU.
-__device__ inline void flip3_step16(const char *nb_base, uint32_t dummy_row, char *Sg, char *Fg, char *log_base, uint32_t log_off,
-                                    uint32_t gl, uint32_t &fs2, uint32_t &nfl)
-{
-    const uint32_t Fg_addr = lds_addr_of(Fg);
-    const uint32_t w2 = fs2 ? (uint32_t)__builtin_ctz(fs2) : 0u;
-    const uint32_t x = *(const uint32_t *)(Fg + (w2 << 6) + gl * 4);
-    uint32_t c;
-    asm("v_ffbl_b32 %0, %1" : "=v"(c) : "v"(x));
-    c |= gl << 5;
-    const uint32_t mpos = row_min_u32(c);
-    const bool found = fs2 != 0 && mpos != NONE;
-    const uint32_t inwin = row_add_u32((uint32_t)__builtin_popcount(x));
-    if (inwin <= 1) fs2 &= fs2 - 1;                             // empty window, or b its only bit: retire it
-    const uint32_t b = found ? (w2 << 9) | mpos : dummy_row;
-    const uint4 r = *(const uint4 *)(nb_base + ((b << 8) + gl * 16u));
-    const uint32_t one = found ? 1u : 0u;
-    if (gl == 0) {                                              // slot 0 is b itself: syndrome ^= H e_b (flip.rs:28-29)
-        atomicXor((uint32_t *)(Sg + (r.y >> 16)), one << (r.y & 31));
-        atomicXor((uint32_t *)(Sg + (r.z >> 16)), one << (r.z & 31));
-        atomicXor((uint32_t *)(Sg + (r.w >> 16)), one << (r.w & 31));
-        *(uint16_t *)(log_base + (log_off + nfl * 2u)) = (uint16_t)b;   // flip.rs:30, deferred
-    }
-    wave_order();
-    uint32_t contrib = 0;
-    {
-        const uint32_t wa = *(const uint32_t *)(Sg + (r.y >> 16)), wb = *(const uint32_t *)(Sg + (r.z >> 16));
-        const uint32_t ab = bit_of(wa, r.y) + bit_of(wb, r.z);
-        if ((r.x & 0x100u) || ab == 1u) {                       // (see flip3_step)
-            const uint32_t wc = *(const uint32_t *)(Sg + (r.w >> 16));
-            const bool fl = ab + bit_of(wc, r.w) >= 2;          // flip.rs:41 for three checks
-            const uint32_t m = one << (r.x & 31);
-            lds_mskor(Fg_addr + (r.x >> 16), m, fl ? m : 0u);
-            if (fl) contrib = 1u << (r.x >> 22);
-        }
-    }
-    fs2 |= row_or_u32(contrib);
-    nfl += one;
-    wave_order();
-}
-
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
 {
     extern __shared__ uint64_t lds[];
@@ -1422,8 +1361,11 @@ __host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32
     return 34 + (uint32_t)(sizeof(Flip4Ctl) / 8) + helpers * (list_cap / 4);
 }
 
-// G = lanes per shot in the flip waves (8: two slots per lane, flip3_step; 16: one slot per lane, flip3_step16),
-// NF + NH = waves of the workgroup (16 for G = 8, one workgroup per CU; 13 for G = 16, two per CU).
+// G = lanes per shot in the flip waves (8: two slots per lane, flip3_step); NF + NH = waves of the workgroup.
+// Forms with 16 lanes per shot (one slot per lane, two workgroups per CU) and with 4 (four slots per lane, 16 shots
+// per wave) were built on the same frame and measured slower (6.8e7 and 6.2e7 against 7.8e7 / 8.7e7 shots/s at C2):
+// sixteen lanes cost 1.6x the instructions per flip on pipes that are 80 % busy, four make the wave's own instruction
+// stream of a pass 1.5x as long.
 template <int NF, bool PROF = false, int G = 8, int NH = 16 - NF, int SV = 0>
 __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a, uint32_t n_slots)
 {
@@ -1640,8 +1582,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
             }
             idle = 0;
         }
-        if (G == 16) flip3_step16((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl);
-        else flip3_step<PROF, SV>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
+        flip3_step<PROF, SV>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
         if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
             if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
@@ -2987,7 +2928,7 @@ uint32_t flip4_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nf)
     return (uint32_t)std::min<size_t>(F4_MAX_SLOTS, (room - hdr) / per);
 }
 
-uint32_t flip4_scratch_pieces() { return 2 * device_cu_count() * F4_LOGS; }   // (up to two workgroups per CU)
+uint32_t flip4_scratch_pieces() { return device_cu_count() * F4_LOGS; }
 
 typedef void (*flip4_fn)(DeviceGraph, Nb3Table, FlipArgs, uint32_t);
 static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
@@ -3004,50 +2945,10 @@ static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
     }
 }
 
-// flip4 with 16 lanes per shot: two workgroups per CU of NF flip waves (4 shots each) + NH service waves
-struct Flip4Wide {
-    flip4_fn fn;
-    uint32_t nf, nh;
-    const char *name;
-};
-static Flip4Wide flip4_wide_for(int sel)
-{
-    switch (sel) {
-    case 1608: return {flip4_kernel<8, false, 16, 4>, 8, 4, "flip4_kernel<8,16 lanes,4>"};
-    case 1610: return {flip4_kernel<10, false, 16, 4>, 10, 4, "flip4_kernel<10,16 lanes,4>"};
-    case 1611: return {flip4_kernel<11, false, 16, 4>, 11, 4, "flip4_kernel<11,16 lanes,4>"};
-    case 1612: return {flip4_kernel<12, false, 16, 4>, 12, 4, "flip4_kernel<12,16 lanes,4>"};
-    case 1609: default: return {flip4_kernel<9, false, 16, 4>, 9, 4, "flip4_kernel<9,16 lanes,4>"};
-    }
-}
-
-// slots of a 16-lane workgroup: half of a CU's LDS
-static uint32_t flip4_wide_slots(const Nb3Table &t, uint32_t list_cap, uint32_t nh)
-{
-    const size_t hdr = (size_t)flip4_hdr_words(list_cap, nh) * 8, per = ((size_t)t.sw + (size_t)t.windows * 8) * 8;
-    const size_t room = 80 * 1024 - 1024;
-    if (hdr + per > room) return 0;
-    return (uint32_t)std::min<size_t>(F4_MAX_SLOTS, (room - hdr) / per);
-}
-
 hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs &a, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
     if (a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
-    if (switches().flip_nf >= 1600) {
-        // (A/B: LDPC_HIP_FLIP_NF = 16xx selects the 16-lane form with xx flip waves per workgroup)
-        const Flip4Wide w = flip4_wide_for(switches().flip_nf);
-        const uint32_t n_slots = flip4_wide_slots(nb, a.list_cap, w.nh);
-        if (n_slots < w.nf * 4 + 1) return hipErrorInvalidValue;
-        const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, w.nh) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * device_cu_count(), (a.n_shots + 63) / 64);
-        hipError_t e = hipFuncSetAttribute((const void *)w.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (switches().debug) std::fprintf(stderr, "[ldpc_hip] %s: %u slots, lds %zu B, grid %u\n", w.name, n_slots, lds, grid);
-        g_kernel_name = w.name;
-        hipLaunchKernelGGL(w.fn, dim3(grid), dim3((w.nf + w.nh) * 64), lds, st, g, nb, a, n_slots);
-        return hipGetLastError();
-    }
     // flip waves of the 16: measured at C2 8 -> 7.2e7, 9 -> 7.6e7 shots/s, 10 -> the service waves do not keep up
     // (LDPC_HIP_FLIP_NF: A/B aid); fewer when the LDS holds fewer slots than their groups plus one per service wave
     uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 9u;
