@@ -549,11 +549,23 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256) || (g.E >= 200 && work_groups <= 128);
     if (switches().bp_path == 1) stream = true;   // A/B and test aid
     else if (switches().bp_path == 2) stream = false;
+    // Small codes with regular checks, calls of up to 2^18 shots: the messages of a shot live in LDS, one workgroup
+    // per shot in flight (bp_lds_kernel).  Measured against the forms above (scripts/bp_lds_small.py, C1 / E = 2100 /
+    // E = 6000): one shot 0.28 -> 0.07 ms, 16,384 shots 2.0x, 131,072 shots 1.1-2.4x, even at 262,144, and behind from
+    // there (0.85-0.9x at 10^6 shots on C1: lane = check costs 31 % more instructions than lane = shot, whose index
+    // arithmetic is scalar; profiles/README.md).  Posterior / message outputs stay with the forms that keep both
+    // message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and forbid it (tests, A/B).
+    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out &&
+                          (switches().bp_path == 3 || (switches().bp_path == 0 && r.n_shots <= (1ull << 18)));
+    if (lds_form) {
+        stream = false;
+        groups = 0;
+    }
     if (stream) groups = std::min<uint64_t>(std::min<uint64_t>(by_memory, 4096), std::max<uint64_t>((r.n_shots + 63) / 64, 1));
     if (switches().bp_groups && stream)   // A/B aid (streamed form only: the persistent grid must stay resident)
         groups = std::max<uint64_t>(1, std::min<uint64_t>(groups, (uint64_t)switches().bp_groups));
     if (switches().debug)
-        std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", stream ? "stream" : "persistent", g.E, waves,
+        std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", lds_form ? "lds" : stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
     HIP_TRY(dec->workspace.reserve(per_group * groups));
 
@@ -600,7 +612,9 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.gap = r.gap;
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);
-    if (stream) {
+    if (lds_form) {
+        HIP_TRY(launch_bp_lds(g, a, dec->reg_dc, g_stream));
+    } else if (stream) {
         HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
         uint64_t rounds = 0;
         HIP_TRY(bp_stream_run(g, a, dec->stream_state.as<char>(), (uint32_t)groups, dec->reg_dc, dec->reg_dv, g_stream, &rounds));

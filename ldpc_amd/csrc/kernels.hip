@@ -2186,6 +2186,213 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 
 
 // ---------------------------------------------------------------------------
+// Belief propagation with the messages of a shot in LDS (small codes: E * 8 bytes beside the shot's words fit a
+// fraction of a CU's 160 KiB).  One workgroup per shot in flight, shots from the device-wide queue; a thread works a
+// check in update_checks and a bit in update_bits.  ONE message array serves both directions: a check's DC entries
+// belong to that check alone and a bit's entries to that bit alone, so update_checks overwrites the tanh of the
+// incoming bit messages with the outgoing check messages in place, and update_bits overwrites those with the tanh of
+// the new bit messages.  The arithmetic is bp_kernel's (bp_check_row, bp_tanh_half, the same orders of the products
+// and sums), so the results are bit-identical to it; nothing of an iteration touches HBM, and a shot that does not
+// converge holds one workgroup, not a 64-slot group.  Posterior / message outputs are left to the other forms.
+// ---------------------------------------------------------------------------
+constexpr uint32_t BPL_THREADS = 320;   // 5 waves: 300 / 900 checks and 625 / 1200 bits (C3, C1) leave few lanes idle
+
+// LDS of a workgroup, in u64 words: messages, error / decision / syndrome / residual words, gap table, queue slot,
+// then the graph as u16 (check -> bits, bit -> edges, bit -> first edge): every index of an iteration comes from LDS
+__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g)
+{
+    const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
+    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + (2 * (size_t)g.E + g.n + 1 + 3) / 4;
+}
+
+template <int DC> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_lds_kernel(DeviceGraph g, BpArgs a)
+{
+    extern __shared__ uint64_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr uint32_t NT = BPL_THREADS;
+    const uint32_t n = g.n, m = g.m, E = g.E, Wn = (n + 63) / 64, Wm = (m + 63) / 64;
+    double *msg = (double *)lds;
+    uint64_t *ew = lds + E, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
+    uint32_t *q = (uint32_t *)(rw + Wm);
+    uint32_t *sh_flag = q + 65;   // (the gap table's 66th word)
+    unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 33);
+    uint16_t *hidx = (uint16_t *)(sh_queue + 1), *tedge = hidx + E, *tptr = tedge + E;
+    uint32_t *dw32 = (uint32_t *)dw, *rw32 = (uint32_t *)rw;
+    const uint32_t *sw32 = (const uint32_t *)sw, *ew32 = (const uint32_t *)ew;
+    for (uint32_t i = tid; i < 65; i += NT) q[i] = a.gap.q[i];
+    for (uint32_t e = tid; e < E; e += NT) {
+        hidx[e] = (uint16_t)g.h_idx[e];
+        tedge[e] = (uint16_t)g.t_edge[e];
+    }
+    for (uint32_t b = tid; b <= n; b += NT) tptr[b] = (uint16_t)g.t_ptr[b];
+    const double prior = a.prior, t_prior = bp_tanh_half(prior);
+    const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;   // thread 0
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *sh_queue = atomicAdd(a.queue, 1ull);
+        __syncthreads();
+        const uint64_t myi = *sh_queue;
+        if (myi >= a.n_shots) break;
+        const uint64_t shot = a.first_shot + myi;
+        // ---- the shot's error word (or the caller's), decision words, messages = the prior (:60-68)
+        for (uint32_t w = tid; w < Wn; w += NT) {
+            const uint32_t nb = bits_in_word(n, w);
+            uint64_t x = 0;
+            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
+            else if (a.source == SRC_WORDS) {
+                x = a.words_in[myi * Wn + w];
+                if (nb < 64) x &= (1ull << nb) - 1;
+            } else if (a.source != SRC_SYNDROMES) {
+                uint64_t xx, zz;
+                depol_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb, xx, zz);
+                x = a.source == SRC_DEPOL_X ? xx : zz;
+            }
+            ew[w] = x;
+            dw[w] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
+        }
+        for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
+        __syncthreads();
+        // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision, 64 checks
+        // per wave and trip: a ballot packs the parities.  The bit update keeps the residual current from then on.
+        for (uint32_t c0 = wv * 64; c0 < m; c0 += NT) {
+            const uint32_t c = c0 + lane;
+            uint32_t par = 0, rpar = 0;
+            if (c < m) {
+                if (a.source == SRC_SYNDROMES) par = (uint32_t)(a.synd_in[myi * Wm + (c >> 6)] >> (c & 63)) & 1u;
+                else {
+#pragma unroll
+                    for (int j = 0; j < DC; j++) {
+                        const uint32_t b = hidx[c * (uint32_t)DC + j];
+                        par ^= (ew32[b >> 5] >> (b & 31)) & 1u;
+                    }
+                }
+                rpar = par ^ (init ? (uint32_t)(DC & 1) : 0u);
+            }
+            const uint64_t mask = __ballot(par != 0), rmask = __ballot(rpar != 0);
+            if (lane == 0) {
+                sw[c0 >> 6] = mask;
+                rw[c0 >> 6] = rmask;
+            }
+        }
+        uint32_t iter = 0;
+        bool conv;
+        for (;;) {
+            // ---- stop test (belief_propagation.rs:26-27): H * decision == syndrome, i.e. the residual is zero (every
+            // wave reads all of it: no flag to share)
+            __syncthreads();
+            {
+                uint32_t r = 0;
+                for (uint32_t w = lane; w < 2 * Wm; w += 64) r |= rw32[w];
+                conv = __ballot(r != 0) == 0;
+            }
+            if (conv || iter >= a.max_iter) break;
+            // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
+            for (uint32_t c = tid; c < m; c += NT) {
+                double x[DC], out[DC];
+#pragma unroll
+                for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
+                const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
+                bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
+#pragma unroll
+                for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
+            }
+            __syncthreads();
+            // ---- update_bits (:168-180) + hard decision (:100-113), in place: check messages in, tanh((sum - own + prior) / 2)
+            // out; 64 consecutive bits per wave and trip, so a ballot is the decision word
+            for (uint32_t b0 = wv * 64; b0 < n; b0 += NT) {
+                const uint32_t b = b0 + lane;
+                bool dec = false, changed = false;
+                if (b < n) {
+                    const uint32_t k0 = tptr[b], dv = tptr[b + 1] - k0;
+                    double sum = 0.0, post = prior;
+                    if (dv <= REG_DEG) {
+                        uint32_t ed[REG_DEG];
+                        double v[REG_DEG];
+#pragma unroll
+                        for (uint32_t k = 0; k < REG_DEG; k++)
+                            if (k < dv) {
+                                ed[k] = tedge[k0 + k];
+                                v[k] = msg[ed[k]];
+                            }
+#pragma unroll
+                        for (uint32_t k = 0; k < REG_DEG; k++)
+                            if (k < dv) {
+                                sum += v[k];
+                                post += v[k];
+                            }
+#pragma unroll
+                        for (uint32_t k = 0; k < REG_DEG; k++)
+                            if (k < dv) msg[ed[k]] = bp_tanh_half(sum - v[k] + prior);
+                    } else {
+                        for (uint32_t k = 0; k < dv; k++) {
+                            const double vv = msg[tedge[k0 + k]];
+                            sum += vv;
+                            post += vv;
+                        }
+                        for (uint32_t k = 0; k < dv; k++) {
+                            const uint32_t e = tedge[k0 + k];
+                            msg[e] = bp_tanh_half(sum - msg[e] + prior);
+                        }
+                    }
+                    dec = post < 0.0;
+                    changed = dec != (((dw32[b >> 5] >> (b & 31)) & 1u) != 0);
+                    if (changed)   // (few bits after the first iteration)
+                        for (uint32_t k = 0; k < dv; k++) {
+                            const uint32_t c = g.t_idx[k0 + k];
+                            atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                        }
+                }
+                const uint64_t mask = __ballot(dec);
+                if (lane == 0) dw[b0 >> 6] = mask;
+            }
+            iter++;
+        }
+        // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
+        const bool det = !conv;
+        bool fail = false;
+        if (a.test != TEST_NONE) {
+            __syncthreads();
+            if (tid == 0) *sh_flag = 0;
+            __syncthreads();
+            uint32_t f = 0;
+            if (a.test == TEST_RESIDUAL) {
+                for (uint32_t w = tid; w < Wn; w += NT) f |= (ew[w] ^ dw[w]) != 0 ? 1u : 0u;
+            } else {
+                for (uint32_t r = tid; r < a.l_rows; r += NT) {
+                    uint32_t par = 0;
+                    for (uint32_t k = a.l_ptr[r]; k < a.l_ptr[r + 1]; k++) {
+                        const uint32_t b = a.l_idx[k];
+                        par ^= ((ew32[b >> 5] ^ dw32[b >> 5]) >> (b & 31)) & 1u;
+                    }
+                    f |= par;
+                }
+            }
+            if (__ballot(f != 0) && lane == 0) *sh_flag = 1;
+            __syncthreads();
+            fail = a.test == TEST_RESIDUAL ? *sh_flag != 0 : det || *sh_flag != 0;
+        }
+        if (a.corr_out)
+            for (uint32_t w = tid; w < Wn; w += NT) a.corr_out[myi * Wn + w] = a.xor_input ? dw[w] ^ ew[w] : dw[w];
+        if (tid == 0) {
+            if (a.iters_out) a.iters_out[myi] = iter;
+            if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
+            c_shots++; c_fail += fail; c_det += det; c_work += iter;
+        }
+    }
+    if (tid == 0 && a.counters) {
+        if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
+        if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
+        if (c_det) {
+            atomicAdd(&a.counters[CNT_DET], (unsigned long long)c_det);
+            atomicAdd(&a.counters[CNT_CAPPED], (unsigned long long)c_det);
+        }
+        if (c_fail > c_det && a.test == TEST_RESIDUAL) atomicAdd(&a.counters[CNT_UNDET], (unsigned long long)(c_fail - c_det));
+        if (c_work) atomicAdd(&a.counters[CNT_WORK], (unsigned long long)c_work);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Belief propagation, streamed form for codes whose message arrays are so large
 // that memory allows fewer 64-shot groups than the chip has room for workgroups
 // (C5: n = 10^6, 3 GB per group).  The same data layout and arithmetic as
@@ -2809,7 +3016,7 @@ Switches read_switches()
     if (const char *e = std::getenv("LDPC_HIP_FLIP_KERNEL")) s.flip_kernel = !std::strcmp(e, "csr") ? 1 : !std::strcmp(e, "v2") ? 2 : !std::strcmp(e, "v3") ? 3 : 0;
     if (const char *e = std::getenv("LDPC_HIP_BP_WAVES")) s.bp_waves = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("LDPC_HIP_BP_OVERSUB")) s.bp_oversub = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) s.bp_path = !std::strcmp(e, "stream") ? 1 : !std::strcmp(e, "persistent") ? 2 : 0;
+    if (const char *e = std::getenv("LDPC_HIP_BP_PATH")) s.bp_path = !std::strcmp(e, "stream") ? 1 : !std::strcmp(e, "persistent") ? 2 : !std::strcmp(e, "lds") ? 3 : !std::strcmp(e, "hbm") ? 4 : 0;
     if (const char *e = std::getenv("LDPC_HIP_BP_GROUPS")) s.bp_groups = std::max(1ll, std::atoll(e));
     if (const char *e = std::getenv("LDPC_HIP_BP_HANDOFF")) {
         s.bp_handoff_set = true;
@@ -3010,6 +3217,53 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
     if (!a.n_shots || !groups) return hipSuccess;
     g_kernel_name = dc == 6 && dv == 3 ? "bp_kernel<6,3>" : dc == 4 && dv == 3 ? "bp_kernel<4,3>" : dc == 7 ? "bp_kernel<7,*>" : "bp_kernel<0,*>";
     hipLaunchKernelGGL(bp_kernel_for(dc, dv), dim3(groups), dim3(64 * waves), 0, st, g, a);
+    return hipGetLastError();
+}
+
+size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g) * 8; }
+
+typedef void (*bp_lds_fn)(DeviceGraph, BpArgs);
+static bp_lds_fn bp_lds_kernel_for(int dc)
+{
+    return dc == 4 ? bp_lds_kernel<4> : dc == 6 ? bp_lds_kernel<6> : dc == 7 ? bp_lds_kernel<7> : dc == 3 ? bp_lds_kernel<3> : (bp_lds_fn) nullptr;
+}
+
+bool bp_lds_serves(const DeviceGraph &g, int dc)
+{
+    return bp_lds_kernel_for(dc) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && bp_lds_bytes(g) <= 150 * 1024;   // (u16 graph copies)
+}
+
+// workgroups of the LDS form that are resident at once (asked once per device and form)
+static uint32_t bp_lds_resident(const DeviceGraph &g, int dc)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void *, size_t>, uint32_t> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *fn = (const void *)bp_lds_kernel_for(dc);
+    const size_t lds = bp_lds_bytes(g);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(std::make_tuple(dev, fn, lds));
+    if (it != cache.end()) return it->second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)BPL_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint32_t r = (uint32_t)per_cu * device_cu_count();
+    cache[std::make_tuple(dev, fn, lds)] = r;
+    return r;
+}
+
+hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, hipStream_t st)
+{
+    if (!a.n_shots) return hipSuccess;
+    const bp_lds_fn k = bp_lds_kernel_for(dc);
+    if (!k || a.post_out || a.chk_out) return hipErrorInvalidValue;
+    const size_t lds = bp_lds_bytes(g);
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, bp_lds_resident(g, dc));
+    if (switches().debug) std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot, %u workgroups\n", lds, grid);
+    g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : "bp_lds_kernel<3>";
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), lds, st, g, a);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ struct Switches {
     int flip_nf = 0;                  // LDPC_HIP_FLIP_NF: flip4 flip waves of the 16 (0: default 8)
     int bp_waves = 0;                 // LDPC_HIP_BP_WAVES (0: by code size)
     int bp_oversub = 1;               // LDPC_HIP_BP_OVERSUB
-    int bp_path = 0;                  // LDPC_HIP_BP_PATH: 0 by size, 1 "stream", 2 "persistent"
+    int bp_path = 0;                  // LDPC_HIP_BP_PATH: 0 by size, 1 "stream", 2 "persistent", 3 "lds" (where it serves), 4 "hbm" (never lds)
     long long bp_groups = 0;          // LDPC_HIP_BP_GROUPS (0: unset)
     bool bp_handoff_set = false;      // LDPC_HIP_BP_HANDOFF given
     uint32_t bp_handoff = 16;
@@ -175,6 +175,9 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
                      hipStream_t st);
 // counters[FAILURES] += #{flags != 0}, [XFAIL] += #{flags & 1}, [ZFAIL] += #{flags & 2}
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
+size_t bp_lds_bytes(const DeviceGraph &g);
+bool bp_lds_serves(const DeviceGraph &g, int dc);   // the LDS-resident BP form holds this code (regular checks, messages within 64 KiB)
+hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, hipStream_t st);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);
 size_t bp_stream_state_bytes(uint32_t groups);

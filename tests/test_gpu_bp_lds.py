@@ -1,0 +1,112 @@
+"""The LDS-resident BP form (bp_lds_kernel: one workgroup per shot, messages of the shot in LDS, a thread per check /
+per bit; small codes with regular checks, calls of up to 2^18 shots) against the persistent and streamed forms and
+the oracle.  All forms run the same arithmetic in the same order (belief_propagation.rs:150-180), so decisions,
+iteration counts, counters and failure flags are compared bit for bit; LDPC_HIP_BP_PATH picks the form."""
+import numpy as np
+import pytest
+
+import ldpc_amd
+from ldpc_amd import (CNT_CAPPED, CNT_DETECTED, CNT_FAILURES, CNT_SHOTS, CNT_WORK, BpDecoder, CssCode, CssDecoder, LinearCode,
+                      nwords)
+from oracle import oracle as orc
+from tests.gpu_util import dev_u32, dev_u64, dev_u8, host_u32, host_u64, oracle_code, to_dev_u64
+
+pytestmark = pytest.mark.gpu
+
+
+def _forms(monkeypatch, fn, forms=("lds", "persistent", "stream")):
+    out = {}
+    for path in forms:
+        monkeypatch.setenv("LDPC_HIP_BP_PATH", path)
+        out[path] = fn()
+        if path == "lds":
+            assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel"), ldpc_amd.last_kernel_name()
+        else:
+            assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+    monkeypatch.delenv("LDPC_HIP_BP_PATH")
+    return out
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("n,m,dv,dc,p,shots,max_iter", [(1200, 900, 3, 4, 0.02, 700, 100), (1200, 900, 3, 4, 0.07, 300, 15),
+                                                        (600, 300, 3, 6, 0.04, 1000, 40), (2000, 1000, 3, 6, 0.03, 200, 100),
+                                                        (700, 300, 3, 7, 0.02, 400, 30), (20, 15, 3, 4, 0.1, 500, 10)])
+def test_lds_correction_for_batch_equals_the_other_forms(monkeypatch, n, m, dv, dc, p, shots, max_iter):
+    code = LinearCode.random_regular_code(n, m, dv, dc, seed=3)
+    oc = oracle_code(code)
+    syn = np.zeros((shots, nwords(m)), dtype=np.uint64)
+    for i in range(shots):
+        syn[i] = oc.syndrome_words(orc.sample_bsc_words(11, i, p, n))
+
+    def run():
+        dec = BpDecoder(code, p, max_iter)
+        dc_, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+        dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di)
+        return host_u64(dc_), host_u32(di)
+
+    out = _forms(monkeypatch, run)
+    assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"])
+    for i in range(0, shots, 29):   # and the oracle on a sample
+        c, it, _ = oc.bp_correction_for(p, max_iter, syn[i])
+        if (out["lds"][0][i] == c).all():
+            assert out["lds"][1][i] == it
+
+
+def test_lds_decode_batch_and_negative_prior(monkeypatch):
+    # p > 0.5: the prior is negative, the decision before the first update is all ones (belief_propagation.rs:100-113)
+    code = LinearCode.random_regular_code(96, 72, 3, 4, seed=2)
+    shots = 300
+    for p in (0.05, 0.6):
+        words = np.stack([orc.sample_bsc_words(5, i, min(p, 0.1), 96) for i in range(shots)]).reshape(shots, nwords(96))
+
+        def run():
+            dec = BpDecoder(code, p, 12)
+            do = dev_u64(words.shape)
+            dec.decode_batch(shots, to_dev_u64(words), do)
+            return (host_u64(do),)
+
+        out = _forms(monkeypatch, run)
+        assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"]), p
+
+
+def test_lds_mc_counters_flags_and_split(monkeypatch):
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+
+    def run():
+        dec = BpDecoder(code, 0.06, 25)
+        flags = dev_u8((5000,))
+        cnt = dec.mc_run(0.06, 2024, 100, 5000, flags)
+        return cnt, flags.cpu().numpy()
+
+    out = _forms(monkeypatch, run)
+    assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"])
+    cnt, flags = out["lds"]
+    assert cnt[CNT_SHOTS] == 5000 and int(flags.sum()) == cnt[CNT_FAILURES] and cnt[CNT_DETECTED] == cnt[CNT_CAPPED]
+    ref = oracle_code(code).mc_bp(0.06, 25, 2024, 100, 5000, nthreads=8)
+    assert abs(int(cnt[CNT_FAILURES]) - int(ref[CNT_FAILURES])) <= 2 and abs(int(cnt[CNT_WORK]) - int(ref[CNT_WORK])) <= 20
+    # shot ranges add up; empty and single-shot calls
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "lds")
+    dec = BpDecoder(code, 0.03, 30)
+    total, a, b = dec.mc_run(0.03, 7, 0, 9000), dec.mc_run(0.03, 7, 0, 4321), dec.mc_run(0.03, 7, 4321, 9000 - 4321)
+    assert ((a + b) == total).all()
+    assert dec.mc_run(0.03, 7, 0, 0)[CNT_SHOTS] == 0 and dec.mc_run(0.03, 7, 0, 1)[CNT_SHOTS] == 1
+
+
+def test_lds_is_the_default_for_small_calls_and_css_agrees(monkeypatch):
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
+    dec = BpDecoder(code, 0.02, 100)
+    dec.mc_run(0.02, 1, 0, 4096)
+    assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+    dec.mc_run(0.02, 1, 0, (1 << 18) + 64)
+    assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+    # CSS: hypergraph product of the (3,4)-regular n = 20 code with itself (the css_decoding example), X and Z halves
+    css = CssCode.hypergraph_product(LinearCode.random_regular_code(20, 15, 3, 4, seed=1), LinearCode.random_regular_code(20, 15, 3, 4, seed=1))
+
+    def run():
+        return (CssDecoder(css, 0.03, 50).mc_run(0.03, 9, 0, 6000),)
+
+    out = _forms(monkeypatch, run, forms=("lds", "persistent"))
+    assert _same(out["lds"], out["persistent"])
