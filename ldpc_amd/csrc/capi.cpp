@@ -549,14 +549,12 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256) || (g.E >= 200 && work_groups <= 128);
     if (switches().bp_path == 1) stream = true;   // A/B and test aid
     else if (switches().bp_path == 2) stream = false;
-    // Small codes with regular checks, calls of up to 2^18 shots: the messages of a shot live in LDS, one workgroup
-    // per shot in flight (bp_lds_kernel).  Measured against the forms above (scripts/bp_lds_small.py, C1 / E = 2100 /
-    // E = 6000): one shot 0.28 -> 0.07 ms, 16,384 shots 2.0x, 131,072 shots 1.1-2.4x, even at 262,144, and behind from
-    // there (0.85-0.9x at 10^6 shots on C1: lane = check costs 31 % more instructions than lane = shot, whose index
-    // arithmetic is scalar; profiles/README.md).  Posterior / message outputs stay with the forms that keep both
-    // message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and forbid it (tests, A/B).
-    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out &&
-                          (switches().bp_path == 3 || (switches().bp_path == 0 && r.n_shots <= (1ull << 18)));
+    // Small codes with regular checks: the messages of a shot live in LDS, one workgroup per shot in flight
+    // (bp_lds_kernel).  Measured against the forms above (scripts/bp_lds_small.py; C1 / (3,4) E = 2100 / (3,6) E = 6000):
+    // one shot 0.3 -> 0.07 ms, 16,384 shots 2.7-3x, 2^21 shots 1.24x / 1.40x / 1.09x; the CSS example's halves (check
+    // degree 7, bits of degree 3 and 4) run level with bp_kernel at 2^22 shots and ahead below.  Posterior / message
+    // outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and forbid it.
+    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out && (switches().bp_path == 3 || switches().bp_path == 0);
     if (lds_form) {
         stream = false;
         groups = 0;
@@ -613,7 +611,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
 
     std::unique_ptr<KernelTimer> timer(time_it ? new KernelTimer() : nullptr);
     if (lds_form) {
-        HIP_TRY(launch_bp_lds(g, a, dec->reg_dc, g_stream));
+        HIP_TRY(launch_bp_lds(g, a, dec->reg_dc, dec->reg_dv, g_stream));
     } else if (stream) {
         HIP_TRY(dec->stream_state.reserve(bp_stream_state_bytes((uint32_t)groups)));
         uint64_t rounds = 0;

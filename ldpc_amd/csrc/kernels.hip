@@ -2205,7 +2205,8 @@ __host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g)
     return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + (2 * (size_t)g.E + g.n + 1 + 3) / 4;
 }
 
-template <int DC> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_lds_kernel(DeviceGraph g, BpArgs a)
+// DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
+template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_lds_kernel(DeviceGraph g, BpArgs a)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2304,26 +2305,27 @@ template <int DC> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_lds_kerne
                 const uint32_t b = b0 + lane;
                 bool dec = false, changed = false;
                 if (b < n) {
-                    const uint32_t k0 = tptr[b], dv = tptr[b + 1] - k0;
+                    constexpr uint32_t RD = DV > 0 ? (uint32_t)DV : DV < 0 ? (uint32_t)(-DV) : REG_DEG;
+                    const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : tptr[b], dv = DV > 0 ? (uint32_t)DV : tptr[b + 1] - k0;
                     double sum = 0.0, post = prior;
-                    if (dv <= REG_DEG) {
-                        uint32_t ed[REG_DEG];
-                        double v[REG_DEG];
+                    if (DV != 0 || dv <= RD) {
+                        uint32_t ed[RD];
+                        double v[RD];
 #pragma unroll
-                        for (uint32_t k = 0; k < REG_DEG; k++)
-                            if (k < dv) {
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) {
                                 ed[k] = tedge[k0 + k];
                                 v[k] = msg[ed[k]];
                             }
 #pragma unroll
-                        for (uint32_t k = 0; k < REG_DEG; k++)
-                            if (k < dv) {
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) {
                                 sum += v[k];
                                 post += v[k];
                             }
 #pragma unroll
-                        for (uint32_t k = 0; k < REG_DEG; k++)
-                            if (k < dv) msg[ed[k]] = bp_tanh_half(sum - v[k] + prior);
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) msg[ed[k]] = bp_tanh_half(sum - v[k] + prior);
                     } else {
                         for (uint32_t k = 0; k < dv; k++) {
                             const double vv = msg[tedge[k0 + k]];
@@ -3223,24 +3225,31 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g) * 8; }
 
 typedef void (*bp_lds_fn)(DeviceGraph, BpArgs);
-static bp_lds_fn bp_lds_kernel_for(int dc)
+static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
 {
-    return dc == 4 ? bp_lds_kernel<4> : dc == 6 ? bp_lds_kernel<6> : dc == 7 ? bp_lds_kernel<7> : dc == 3 ? bp_lds_kernel<3> : (bp_lds_fn) nullptr;
+    const int v = dv == 3 ? 3 : (dv == -4 || (dv >= 1 && dv <= 4)) ? -4 : 0;
+    switch (dc) {
+    case 3: return v == 3 ? bp_lds_kernel<3, 3> : v == -4 ? bp_lds_kernel<3, -4> : bp_lds_kernel<3, 0>;
+    case 4: return v == 3 ? bp_lds_kernel<4, 3> : v == -4 ? bp_lds_kernel<4, -4> : bp_lds_kernel<4, 0>;
+    case 6: return v == 3 ? bp_lds_kernel<6, 3> : v == -4 ? bp_lds_kernel<6, -4> : bp_lds_kernel<6, 0>;
+    case 7: return v == 3 ? bp_lds_kernel<7, 3> : v == -4 ? bp_lds_kernel<7, -4> : bp_lds_kernel<7, 0>;
+    default: return nullptr;
+    }
 }
 
 bool bp_lds_serves(const DeviceGraph &g, int dc)
 {
-    return bp_lds_kernel_for(dc) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && bp_lds_bytes(g) <= 150 * 1024;   // (u16 graph copies)
+    return bp_lds_kernel_for(dc, 0) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && bp_lds_bytes(g) <= 150 * 1024;   // (u16 graph copies)
 }
 
 // workgroups of the LDS form that are resident at once (asked once per device and form)
-static uint32_t bp_lds_resident(const DeviceGraph &g, int dc)
+static uint32_t bp_lds_resident(const DeviceGraph &g, int dc, int dv)
 {
     static std::mutex mu;
     static std::map<std::tuple<int, const void *, size_t>, uint32_t> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const void *fn = (const void *)bp_lds_kernel_for(dc);
+    const void *fn = (const void *)bp_lds_kernel_for(dc, dv);
     const size_t lds = bp_lds_bytes(g);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(std::make_tuple(dev, fn, lds));
@@ -3252,15 +3261,15 @@ static uint32_t bp_lds_resident(const DeviceGraph &g, int dc)
     return r;
 }
 
-hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, hipStream_t st)
+hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
-    const bp_lds_fn k = bp_lds_kernel_for(dc);
+    const bp_lds_fn k = bp_lds_kernel_for(dc, dv);
     if (!k || a.post_out || a.chk_out) return hipErrorInvalidValue;
     const size_t lds = bp_lds_bytes(g);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, bp_lds_resident(g, dc));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, bp_lds_resident(g, dc, dv));
     if (switches().debug) std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot, %u workgroups\n", lds, grid);
     g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : "bp_lds_kernel<3>";
     hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), lds, st, g, a);

@@ -177,7 +177,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
 size_t bp_lds_bytes(const DeviceGraph &g);
 bool bp_lds_serves(const DeviceGraph &g, int dc);   // the LDS-resident BP form holds this code (regular checks, messages within 64 KiB)
-hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, hipStream_t st);
+hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);
 size_t bp_stream_state_bytes(uint32_t groups);

@@ -16,7 +16,7 @@ def run(dec, p, shots, path):
 for name, shape, p in (("C1", (1200, 900, 3, 4), 0.02), ("e2100", (700, 525, 3, 4), 0.02), ("e6000", (2000, 1000, 3, 6), 0.02), ("e12000", (4000, 2000, 3, 6), 0.02)):
     code = L.LinearCode.random_regular_code(*shape, seed=1)
     dec = L.BpDecoder(code, p, 100)
-    for shots in (1, 1024, 16384, 131072, 262144, 524288):
+    for shots in (1, 1024, 16384, 131072, 524288, 2097152):
         th, ch = run(dec, p, shots, "hbm")
         tl, cl = run(dec, p, shots, "lds")
         assert ch == cl, (ch, cl)

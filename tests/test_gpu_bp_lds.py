@@ -1,5 +1,5 @@
 """The LDS-resident BP form (bp_lds_kernel: one workgroup per shot, messages of the shot in LDS, a thread per check /
-per bit; small codes with regular checks, calls of up to 2^18 shots) against the persistent and streamed forms and
+per bit; small codes with regular checks) against the persistent and streamed forms and
 the oracle.  All forms run the same arithmetic in the same order (belief_propagation.rs:150-180), so decisions,
 iteration counts, counters and failure flags are compared bit for bit; LDPC_HIP_BP_PATH picks the form."""
 import numpy as np
@@ -95,12 +95,14 @@ def test_lds_mc_counters_flags_and_split(monkeypatch):
     assert dec.mc_run(0.03, 7, 0, 0)[CNT_SHOTS] == 0 and dec.mc_run(0.03, 7, 0, 1)[CNT_SHOTS] == 1
 
 
-def test_lds_is_the_default_for_small_calls_and_css_agrees(monkeypatch):
+def test_lds_is_the_default_where_it_serves_and_css_agrees(monkeypatch):
     code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
     dec = BpDecoder(code, 0.02, 100)
     dec.mc_run(0.02, 1, 0, 4096)
     assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
-    dec.mc_run(0.02, 1, 0, (1 << 18) + 64)
+    # a code whose messages do not fit (C2: 240 KB per shot) keeps the other forms
+    big = BpDecoder(LinearCode.random_regular_code(10000, 5000, 3, 6, seed=1), 0.02, 100)
+    big.mc_run(0.02, 1, 0, 256)
     assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
     # CSS: hypergraph product of the (3,4)-regular n = 20 code with itself (the css_decoding example), X and Z halves
     css = CssCode.hypergraph_product(LinearCode.random_regular_code(20, 15, 3, 4, seed=1), LinearCode.random_regular_code(20, 15, 3, 4, seed=1))
