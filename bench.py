@@ -86,8 +86,15 @@ def replayed_ratio(path):
         return None
 
 
-def bp_roofline(alg_bytes, ms, pmc):
+def bp_roofline(alg_bytes, ms, pmc, kernel=""):
+    """alg_bytes: 32 * E per shot-iteration ACTUALLY RUN (ldpc_last_bp_executed_iterations: the LDS form ends a run that
+    is found to repeat with period two early, and those skipped iterations are not priced)."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
+    if kernel.startswith("bp_lds_kernel"):
+        # a shot's messages live in LDS: the algorithmic bytes never reach HBM, the figure is an equivalent rate
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "traffic_source": None, "note": "LDS-resident form: the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic, "
+                                                "HBM sees only the graph and the outputs; frac is that equivalent rate over the HBM peak"}
     ratio = replayed_ratio(pmc)
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None if ratio is None else ratio * alg_bytes,
@@ -126,11 +133,30 @@ def bp_line(code, shots=1 << 23):
     dec = BpDecoder(code, P, 100)
     dec.mc_run(P, NOISE_SEED, 1 << 40, 8192)
     cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
-    ms = ldpc_amd.last_kernel_ms()
+    ms, ran, kernel = ldpc_amd.last_kernel_ms(), ldpc_amd.last_bp_executed_iterations(), ldpc_amd.last_kernel_name()
     return {"workload": "same code and channel, BpDecoder f64, max 100 iterations, %d shots" % shots,
-            "shots_per_s": shots / (ms * 1e-3), "kernel": ldpc_amd.last_kernel_name(), "kernel_ms": ms,
-            "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges(), ms, BP_PMC)}
+            "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
+            "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
+            "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, BP_PMC, kernel)}
+
+
+def bp_c1_line(shots=1 << 22):
+    """Secondary measurement: configs[0]'s code, (3,4)-regular n = 1200, BSC p = 0.02, BpDecoder f64 max 100 iterations:
+    the LDS-resident BP form (a shot's 28.8 KB of messages in LDS, one workgroup per shot in flight)."""
+    import ldpc_amd
+    from ldpc_amd import BpDecoder, LinearCode
+    code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=CODE_SEED)
+    dec = BpDecoder(code, P, 100)
+    dec.mc_run(P, NOISE_SEED, 1 << 40, 8192)
+    cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
+    ms, ran, kernel = ldpc_amd.last_kernel_ms(), ldpc_amd.last_bp_executed_iterations(), ldpc_amd.last_kernel_name()
+    return {"workload": "configs[0] code: random (3,4)-regular LDPC n=1200 m=900, BSC p=0.02, BpDecoder f64, max 100 iterations, "
+                        "%d shots" % shots,
+            "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
+            "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
+            "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, "profiles/r02_bp_c1_pmc.json", kernel)}
 
 
 def css_line(shots=1 << 23):
@@ -145,13 +171,15 @@ def css_line(shots=1 << 23):
     dec = CssDecoder(css, 0.01, 100)
     dec.mc_run(0.01, NOISE_SEED, 1 << 40, 4096)
     cnt = dec.mc_run(0.01, NOISE_SEED, 0, shots)
-    ms = ldpc_amd.last_kernel_ms()
+    ms, ran, kernel = ldpc_amd.last_kernel_ms(), ldpc_amd.last_bp_executed_iterations(), ldpc_amd.last_kernel_name()
     return {"workload": "configs[2]: CSS hypergraph-product code, 625 qubits (Hx, Hz 300 x 625, row weight 7), depolarizing "
                         "p=0.01, BP f64 max 100 iterations on each half, logical failure test, %d shots" % shots,
-            "shots_per_s": shots / (ms * 1e-3), "kernel": "bp_kernel<7,-4> (+ streamed tail)", "kernel_ms": ms,
+            "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot_both_halves": int(cnt[ldpc_amd.CNT_WORK]) / shots,
+            # runs that never converge (5 % of the shots) alternate between two states: found out exactly and ended early
+            "iterations_run_per_shot_both_halves": ran / shots,
             "logical_failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges, ms, CSS_PMC)}
+            "roofline": bp_roofline(ran * 32 * edges, ms, CSS_PMC, kernel)}
 
 
 def bp_c5_line(shots=70656):
@@ -164,6 +192,7 @@ def bp_c5_line(shots=70656):
     dec.mc_run(P, NOISE_SEED, 1 << 40, 64)
     cnt = dec.mc_run(P, NOISE_SEED, 0, shots)
     ms = ldpc_amd.last_kernel_ms()
+    assert ldpc_amd.last_bp_executed_iterations() == int(cnt[ldpc_amd.CNT_WORK])   # (the streamed form runs every iteration it reports)
     return {"workload": "configs[4]: random (3,6)-regular LDPC n=1000000 m=500000, BSC p=0.02, BpDecoder f64, max 100 "
                         "iterations, %d shots" % shots,
             "shots_per_s": shots / (ms * 1e-3), "kernels": "bps_iterate<6,3> + set-up / stop-test / harvest kernels",
@@ -317,6 +346,7 @@ def finish_line(line, args, world, use_bp, code, counters, avg_kernel_s):
             line["bp"] = bp_line(code)
             line["bp_c5"] = bp_c5_line()
             line["css"] = css_line()
+            line["bp_c1"] = bp_c1_line()
         if use_bp:
             # BP step: algorithmic bytes = 32 E per shot-iteration, iterations from the all-reduced counter
             alg = float(counters[ldpc_amd.CNT_WORK]) / world / args.steps * 32 * code.num_edges()

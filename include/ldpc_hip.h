@@ -82,6 +82,11 @@ double ldpc_last_kernel_ms(void);
 /* Name of the decoding kernel this thread launched last (the library picks among several forms of a decoder by
  * code and batch size; bench.py names the one it timed).  No counterpart in the reference. */
 const char *ldpc_last_kernel_name(void);
+/* BP iterations that the calling thread's last Monte-Carlo call (ldpc_bp_mc_run, ldpc_css_bp_mc_run: both halves)
+ * actually ran.  The counters report what belief_propagation.rs:23-30 would have run (LDPC_CNT_WORK); the LDS form of
+ * the decoder runs fewer when a run that never converges is found to repeat itself with period two, which decides its
+ * result at max_iterations exactly.  bench.py prices its roofline on this number.  No counterpart in the reference. */
+uint64_t ldpc_last_bp_executed_iterations(void);
 /* The LDPC_HIP_* environment variables (A/B, test and profiling switches; none is needed in production) are read
  * once, when the library first needs one.  A test that changes one afterwards calls this to have them read again.
  * No counterpart in the reference (it has no configuration).  Not to be called while other

@@ -72,6 +72,7 @@ def lib():
         "ldpc_last_kernel_ms": (dbl, []),
         "ldpc_debug_reload_switches": (None, []),
         "ldpc_last_kernel_name": (C.c_char_p, []),
+        "ldpc_last_bp_executed_iterations": (C.c_uint64, []),
         "ldpc_code_create": (i, [sz, sz, vp, vp, pp]),
         "ldpc_code_hamming": (i, [pp]),
         "ldpc_code_repetition": (i, [sz, pp]),
@@ -189,6 +190,11 @@ def last_kernel_ms():
 
 def last_kernel_name():
     return lib().ldpc_last_kernel_name().decode("ascii", "replace")
+
+
+def last_bp_executed_iterations():
+    """BP iterations the last mc_run of this thread actually ran (<= its CNT_WORK: periodic runs are cut short)."""
+    return int(lib().ldpc_last_bp_executed_iterations())
 
 
 def reload_switches():

@@ -272,20 +272,27 @@ void export_csr(const SparseBinMat &m, size_t *row_ptr, size_t *col_idx)
     for (size_t i = 0; i < m.idx.size(); i++) col_idx[i] = m.idx[i];
 }
 
-int read_counters(DeviceBuffer &d, uint64_t *out)
+// iterations the calling thread's last BP call actually ran (ldpc_last_bp_executed_iterations)
+thread_local uint64_t g_bp_executed = 0;
+
+// the counters of a handle: LDPC_COUNTERS of them, then the work-queue word, the hand-off flag (bp_kernel) and the
+// count of iterations actually run (bp_lds_kernel)
+constexpr int COUNTER_WORDS = LDPC_COUNTERS + 3;
+
+int read_counters(DeviceBuffer &d, uint64_t *out, uint64_t *executed = nullptr)
 {
-    unsigned long long tmp[LDPC_COUNTERS];
+    unsigned long long tmp[COUNTER_WORDS];
     HIP_TRY(hipMemcpyAsync(tmp, d.p, sizeof(tmp), hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     for (int i = 0; i < LDPC_COUNTERS; i++) out[i] = tmp[i];
+    if (executed) *executed = tmp[LDPC_COUNTERS + 2];
     return LDPC_OK;
 }
 
 int zero_counters(DeviceBuffer &d)
 {
-    // LDPC_COUNTERS counters followed by the work-queue word and the hand-off flag (bp_kernel)
-    HIP_TRY(d.reserve(sizeof(unsigned long long) * (LDPC_COUNTERS + 2)));
-    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * (LDPC_COUNTERS + 2), g_stream));
+    HIP_TRY(d.reserve(sizeof(unsigned long long) * COUNTER_WORDS));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * COUNTER_WORDS, g_stream));
     return LDPC_OK;
 }
 
@@ -565,7 +572,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", lds_form ? "lds" : stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
-    HIP_TRY(dec->workspace.reserve(per_group * groups));
+    if (lds_form) HIP_TRY(dec->workspace.reserve((size_t)bp_lds_workgroups(g, dec->reg_dc, dec->reg_dv) * g.E * 8));   // (saved states, bp_lds_kernel)
+    else HIP_TRY(dec->workspace.reserve(per_group * groups));
 
     BpArgs a{};
     a.source = r.source;
@@ -587,6 +595,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.failed_out = r.failed_out;
     a.counters = dec->counters.as<unsigned long long>();
     a.queue = dec->counters.as<unsigned long long>() + LDPC_COUNTERS;   // zeroed with the counters
+    a.executed = dec->counters.as<unsigned long long>() + LDPC_COUNTERS + 2;
     if (r.logicals) {
         a.l_rows = r.logicals->dg.m;
         a.l_ptr = r.logicals->dg.h_ptr;
@@ -651,7 +660,14 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
         }
     }
     if (timer) timer->stop_and_store();
-    if (counters_out) return read_counters(dec->counters, counters_out);
+    g_bp_executed = 0;
+    if (counters_out) {
+        uint64_t ran = 0;
+        const int rc = read_counters(dec->counters, counters_out, &ran);
+        // (only the LDS form can run fewer iterations than it reports)
+        g_bp_executed = lds_form ? ran : counters_out[LDPC_CNT_WORK];
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(g_stream));
     return LDPC_OK;
 }
@@ -721,6 +737,7 @@ double ldpc_last_kernel_ms(void) { return g_last_ms; }
 void ldpc_debug_reload_switches(void) { reload_switches(); }
 
 const char *ldpc_last_kernel_name(void) { return last_launched_kernel(); }
+uint64_t ldpc_last_bp_executed_iterations(void) { return g_bp_executed; }
 
 // ---- LinearCode -----------------------------------------------------------
 int ldpc_code_create(size_t n_bits, size_t n_checks, const size_t *row_ptr, const size_t *col_idx, ldpc_code **out)
@@ -1647,6 +1664,7 @@ try {
     GapTable gap = make_gap_table(noise_probability);
     const size_t chunk_max = (size_t)1 << 28;
     double ms_total = 0.0;
+    uint64_t ran_total = 0;   // iterations actually run, both halves (ldpc_last_bp_executed_iterations)
     // Small runs (the streamed kernels: at most 128 groups of work) decode the two halves side by side, see below:
     // 1000 shots of the 625-qubit code 13.7 -> 7.3 ms.  Large runs do not: two persistent kernels on two streams were
     // seen to run one after the other, each on half of the workgroup slots (8.4e6 shots: 1.24 -> 1.65 s).
@@ -1692,6 +1710,7 @@ try {
             int st_x = LDPC_OK;
             std::string err_x;
             double ms_x = 0.0;
+            uint64_t ran_x = 0;
             auto x_half = [&]() {
                 hipStream_t sx = nullptr;
                 if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&sx, hipStreamNonBlocking) != hipSuccess) {
@@ -1703,6 +1722,7 @@ try {
                 st_x = run_bp(&dec->x, rx, cz);
                 if (st_x) err_x = g_error;
                 ms_x = g_last_ms;
+                ran_x = g_bp_executed;   // (this half's thread: thread-local)
                 (void)hipStreamSynchronize(sx);
                 (void)hipStreamDestroy(sx);
             };
@@ -1722,6 +1742,7 @@ try {
             } else {
                 g_stream = sz;
                 st = run_bp(&dec->z, rz, cx);
+                ran_total += g_bp_executed;
                 (void)hipStreamSynchronize(sz);
                 (void)hipStreamDestroy(sz);
                 g_stream = caller;
@@ -1736,14 +1757,17 @@ try {
             }
             if (st) return st;
             if (st_x) return fail(st_x, err_x);
+            ran_total += ran_x;
             ms_total += std::max(ms_z, ms_x);
         } else {
             int st = run_bp(&dec->z, rz, cx);
             if (st) return st;
             ms_total += g_last_ms;
+            ran_total += g_bp_executed;
             st = run_bp(&dec->x, rx, cz);
             if (st) return st;
             ms_total += g_last_ms;
+            ran_total += g_bp_executed;
         }
         int st = 0;
         st = zero_counters(dec->counters);
@@ -1760,6 +1784,7 @@ try {
         done += chunk;
     }
     g_last_ms = ms_total;
+    g_bp_executed = ran_total;
     return LDPC_OK;
 }
 LDPC_CATCH

@@ -2228,7 +2228,15 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
     for (uint32_t b = tid; b <= n; b += NT) tptr[b] = (uint16_t)g.t_ptr[b];
     const double prior = a.prior, t_prior = bp_tanh_half(prior);
     const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
-    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0;   // thread 0
+    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0, c_ran = 0;   // thread 0
+    // A run that never converges ends up repeating itself: on the degenerate quantum codes every such run alternates
+    // between two states from about its tenth iteration on.  The update is a function of the bit messages alone, so
+    // once they equal, bit for bit, those of two iterations before, the run is periodic for good: its stop tests keep
+    // failing as they did in the last two iterations, and the decisions after max_iter iterations are the current
+    // ones or the next ones, by parity.  From the sixth iteration on the even iterations leave their bit messages in
+    // `saved` (global, this workgroup's) and compare with what is there; a periodic run takes at most one more
+    // iteration and reports max_iter.  Results and counters are those of the full run (tests/test_gpu_bp_lds.py).
+    unsigned long long *saved = a.msg ? (unsigned long long *)a.msg + (size_t)blockIdx.x * E : nullptr;
     for (;;) {
         __syncthreads();
         if (tid == 0) *sh_queue = atomicAdd(a.queue, 1ull);
@@ -2276,8 +2284,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                 rw[c0 >> 6] = rmask;
             }
         }
-        uint32_t iter = 0;
-        bool conv;
+        uint32_t iter = 0, ran = 0;
+        bool conv, compared = false, last_one = false;
         for (;;) {
             // ---- stop test (belief_propagation.rs:26-27): H * decision == syndrome, i.e. the residual is zero (every
             // wave reads all of it: no flag to share)
@@ -2287,7 +2295,21 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                 for (uint32_t w = lane; w < 2 * Wm; w += 64) r |= rw32[w];
                 conv = __ballot(r != 0) == 0;
             }
+            bool periodic = false;
+            if (compared) {   // (wave-uniform, the same in every wave: a second barrier before the flag is reused)
+                periodic = *sh_flag == 0;
+                __syncthreads();
+            }
             if (conv || iter >= a.max_iter) break;
+            if (last_one || (periodic && !((a.max_iter - iter) & 1u))) {
+                iter = a.max_iter;   // the run would go on alternating between this state and the last one
+                break;
+            }
+            last_one = periodic;
+            const uint32_t t = iter + 1;
+            const bool save = saved != nullptr && t >= 6 && !(t & 1u) && !last_one;
+            compared = save && t >= 8;
+            if (compared && tid == 0) *sh_flag = 0;
             // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
             for (uint32_t c = tid; c < m; c += NT) {
                 double x[DC], out[DC];
@@ -2348,7 +2370,18 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                 const uint64_t mask = __ballot(dec);
                 if (lane == 0) dw[b0 >> 6] = mask;
             }
+            if (save) {   // (wave-uniform; only runs that are still going after five iterations come here)
+                __syncthreads();
+                bool differs = false;
+                for (uint32_t e = tid; e < E; e += NT) {
+                    const unsigned long long nb = (unsigned long long)__double_as_longlong(msg[e]);
+                    if (compared && saved[e] != nb) differs = true;
+                    saved[e] = nb;
+                }
+                if (compared && __ballot(differs) && lane == 0) *sh_flag = 1;
+            }
             iter++;
+            ran++;
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
         const bool det = !conv;
@@ -2379,9 +2412,10 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
         if (tid == 0) {
             if (a.iters_out) a.iters_out[myi] = iter;
             if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
-            c_shots++; c_fail += fail; c_det += det; c_work += iter;
+            c_shots++; c_fail += fail; c_det += det; c_work += iter; c_ran += ran;
         }
     }
+    if (tid == 0 && a.executed && c_ran) atomicAdd(a.executed, (unsigned long long)c_ran);
     if (tid == 0 && a.counters) {
         if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
         if (c_fail) atomicAdd(&a.counters[CNT_FAIL], (unsigned long long)c_fail);
@@ -3260,6 +3294,8 @@ static uint32_t bp_lds_resident(const DeviceGraph &g, int dc, int dv)
     cache[std::make_tuple(dev, fn, lds)] = r;
     return r;
 }
+
+uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv) { return bp_lds_resident(g, dc, dv); }
 
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st)
 {

@@ -97,6 +97,7 @@ struct BpArgs {
     double prior;               // ln((1-p)/p), belief_propagation.rs:38
     uint64_t seed, first_shot, n_shots;
     unsigned long long *queue;  // device counter, zero at launch: shots handed out so far
+    unsigned long long *executed;   // device counter or null: iterations actually run (bp_lds_kernel cuts periodic runs short)
     const uint64_t *words_in;   // [n_shots][Wn]
     const uint64_t *synd_in;    // [n_shots][Wm]
     uint64_t *corr_out;         // [n_shots][Wn] or null
@@ -177,6 +178,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
 size_t bp_lds_bytes(const DeviceGraph &g);
 bool bp_lds_serves(const DeviceGraph &g, int dc);   // the LDS-resident BP form holds this code (regular checks, messages within 64 KiB)
+uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv);   // its grid; a.msg = that many x E u64 of scratch (or null)
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);

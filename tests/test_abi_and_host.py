@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "ldpc_hip.h")).read()
-    declared = set(re.findall(r"^(?:const char \*|const ldpc_code \*|int |size_t |double |void )(ldpc_[a-z0-9_]+)\(",
+    declared = set(re.findall(r"^(?:const char \*|const ldpc_code \*|int |size_t |uint64_t |double |void )(ldpc_[a-z0-9_]+)\(",
                               header, flags=re.M))
     assert len(declared) >= 45
     L = ldpc_amd.lib()

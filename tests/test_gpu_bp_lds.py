@@ -112,3 +112,43 @@ def test_lds_is_the_default_where_it_serves_and_css_agrees(monkeypatch):
 
     out = _forms(monkeypatch, run, forms=("lds", "persistent"))
     assert _same(out["lds"], out["persistent"])
+
+
+@pytest.mark.parametrize("max_iter", [9, 30, 31, 100])
+def test_lds_cuts_periodic_runs_short_and_changes_nothing(monkeypatch, max_iter):
+    """Runs that never converge on the degenerate HGP code alternate between two states from about their tenth
+    iteration on; the LDS form notices (bit messages equal to those of two iterations before) and stops, reporting
+    what the full run reports.  Decisions and iteration counts against the persistent kernel, bit for bit, for both
+    parities of the iterations left; the executed-iteration count shows that runs were in fact cut."""
+    base = LinearCode.random_regular_code(20, 15, 3, 4, seed=1)
+    css = CssCode.hypergraph_product(base, base)
+    hx = css.x_stabs_binary()
+    n, m, shots, p = hx.len(), hx.num_checks(), 3000, 0.02
+    oc = oracle_code(hx)
+    syn = np.zeros((shots, nwords(m)), dtype=np.uint64)
+    for i in range(shots):
+        syn[i] = oc.syndrome_words(orc.sample_bsc_words(3, i, p, n))
+
+    def run():
+        dec = BpDecoder(hx, p, max_iter)
+        dc_, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+        dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di)
+        return host_u64(dc_), host_u32(di)
+
+    out = _forms(monkeypatch, run, forms=("lds", "persistent"))
+    assert _same(out["lds"], out["persistent"])
+    capped = int((out["lds"][1] == max_iter).sum())
+    assert capped > 20, capped            # the case is there
+    # Monte-Carlo counters, and the iterations actually run
+    res = {}
+    for path in ("lds", "persistent"):
+        monkeypatch.setenv("LDPC_HIP_BP_PATH", path)
+        cnt = BpDecoder(hx, p, max_iter).mc_run(p, 3, 0, shots)
+        res[path] = (cnt, ldpc_amd.last_bp_executed_iterations())
+    monkeypatch.delenv("LDPC_HIP_BP_PATH")
+    assert (res["lds"][0] == res["persistent"][0]).all()
+    assert res["persistent"][1] == res["persistent"][0][CNT_WORK]
+    if max_iter >= 30:
+        assert res["lds"][1] < res["lds"][0][CNT_WORK]
+    else:
+        assert res["lds"][1] == res["lds"][0][CNT_WORK]
