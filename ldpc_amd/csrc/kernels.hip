@@ -2196,17 +2196,22 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 // converge holds one workgroup, not a 64-slot group.  Posterior / message outputs are left to the other forms.
 // ---------------------------------------------------------------------------
 constexpr uint32_t BPL_THREADS = 320;   // 5 waves: 300 / 900 checks and 625 / 1200 bits (C3, C1) leave few lanes idle
+#ifndef BPL_WAVES_PER_SIMD
+#define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
+#endif
 
 // LDS of a workgroup, in u64 words: messages, error / decision / syndrome / residual words, gap table, queue slot,
-// then the graph as u16 (check -> bits, bit -> edges, bit -> first edge): every index of an iteration comes from LDS
-__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g)
+// then copies of the graph as u16 when they do not cost a resident workgroup (copies >= 1: bit -> edges, and bit ->
+// first edge for codes with bits of mixed degree; 2: check -> bits as well)
+__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t copies, bool mixed_bits)
 {
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + (2 * (size_t)g.E + g.n + 1 + 3) / 4;
+    const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0);
+    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + (u16s + 3) / 4;
 }
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
-template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_lds_kernel(DeviceGraph g, BpArgs a)
+template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2217,15 +2222,21 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
     uint32_t *q = (uint32_t *)(rw + Wm);
     uint32_t *sh_flag = q + 65;   // (the gap table's 66th word)
     unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 33);
-    uint16_t *hidx = (uint16_t *)(sh_queue + 1), *tedge = hidx + E, *tptr = tedge + E;
+    uint16_t *tedge = (uint16_t *)(sh_queue + 1), *tptr = tedge + E, *hidx = tptr + (DV > 0 ? 0 : n + 1);
+    const bool c_edges = copies >= 1, c_checks = copies >= 2;
+    auto edge_of = [&](uint32_t k) -> uint32_t { return c_edges ? (uint32_t)tedge[k] : g.t_edge[k]; };
+    auto first_edge = [&](uint32_t b) -> uint32_t { return c_edges ? (uint32_t)tptr[b] : g.t_ptr[b]; };
+    auto bit_of_check = [&](uint32_t e) -> uint32_t { return c_checks ? (uint32_t)hidx[e] : g.h_idx[e]; };
     uint32_t *dw32 = (uint32_t *)dw, *rw32 = (uint32_t *)rw;
     const uint32_t *sw32 = (const uint32_t *)sw, *ew32 = (const uint32_t *)ew;
     for (uint32_t i = tid; i < 65; i += NT) q[i] = a.gap.q[i];
-    for (uint32_t e = tid; e < E; e += NT) {
-        hidx[e] = (uint16_t)g.h_idx[e];
-        tedge[e] = (uint16_t)g.t_edge[e];
+    if (c_edges) {
+        for (uint32_t e = tid; e < E; e += NT) tedge[e] = (uint16_t)g.t_edge[e];
+        if (DV <= 0)
+            for (uint32_t b = tid; b <= n; b += NT) tptr[b] = (uint16_t)g.t_ptr[b];
     }
-    for (uint32_t b = tid; b <= n; b += NT) tptr[b] = (uint16_t)g.t_ptr[b];
+    if (c_checks)
+        for (uint32_t e = tid; e < E; e += NT) hidx[e] = (uint16_t)g.h_idx[e];
     const double prior = a.prior, t_prior = bp_tanh_half(prior);
     const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
     uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0, c_ran = 0;   // thread 0
@@ -2272,7 +2283,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                 else {
 #pragma unroll
                     for (int j = 0; j < DC; j++) {
-                        const uint32_t b = hidx[c * (uint32_t)DC + j];
+                        const uint32_t b = bit_of_check(c * (uint32_t)DC + j);
                         par ^= (ew32[b >> 5] >> (b & 31)) & 1u;
                     }
                 }
@@ -2328,7 +2339,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                 bool dec = false, changed = false;
                 if (b < n) {
                     constexpr uint32_t RD = DV > 0 ? (uint32_t)DV : DV < 0 ? (uint32_t)(-DV) : REG_DEG;
-                    const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : tptr[b], dv = DV > 0 ? (uint32_t)DV : tptr[b + 1] - k0;
+                    const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), dv = DV > 0 ? (uint32_t)DV : first_edge(b + 1) - k0;
                     double sum = 0.0, post = prior;
                     if (DV != 0 || dv <= RD) {
                         uint32_t ed[RD];
@@ -2336,7 +2347,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
                             if (DV > 0 || k < dv) {
-                                ed[k] = tedge[k0 + k];
+                                ed[k] = edge_of(k0 + k);
                                 v[k] = msg[ed[k]];
                             }
 #pragma unroll
@@ -2350,12 +2361,12 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, 4) void bp_l
                             if (DV > 0 || k < dv) msg[ed[k]] = bp_tanh_half(sum - v[k] + prior);
                     } else {
                         for (uint32_t k = 0; k < dv; k++) {
-                            const double vv = msg[tedge[k0 + k]];
+                            const double vv = msg[edge_of(k0 + k)];
                             sum += vv;
                             post += vv;
                         }
                         for (uint32_t k = 0; k < dv; k++) {
-                            const uint32_t e = tedge[k0 + k];
+                            const uint32_t e = edge_of(k0 + k);
                             msg[e] = bp_tanh_half(sum - msg[e] + prior);
                         }
                     }
@@ -3256,9 +3267,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
     return hipGetLastError();
 }
 
-size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g) * 8; }
-
-typedef void (*bp_lds_fn)(DeviceGraph, BpArgs);
+typedef void (*bp_lds_fn)(DeviceGraph, BpArgs, uint32_t);
 static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
 {
     const int v = dv == 3 ? 3 : (dv == -4 || (dv >= 1 && dv <= 4)) ? -4 : 0;
@@ -3271,44 +3280,62 @@ static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
     }
 }
 
+// smallest LDS footprint of a workgroup (no graph copies)
+size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g, 0, false) * 8; }
+
 bool bp_lds_serves(const DeviceGraph &g, int dc)
 {
     return bp_lds_kernel_for(dc, 0) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && bp_lds_bytes(g) <= 150 * 1024;   // (u16 graph copies)
 }
 
-// workgroups of the LDS form that are resident at once (asked once per device and form)
-static uint32_t bp_lds_resident(const DeviceGraph &g, int dc, int dv)
+// The launch shape of the LDS form for a code: as many graph copies in LDS as cost no resident workgroup (asked of the
+// runtime once per device, kernel form and footprint)
+struct BpLdsShape {
+    uint32_t copies, workgroups;
+    size_t lds;
+};
+static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, const void *, size_t>, uint32_t> cache;
+    static std::map<std::tuple<int, const void *, uint32_t, uint32_t, uint32_t>, BpLdsShape> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void *fn = (const void *)bp_lds_kernel_for(dc, dv);
-    const size_t lds = bp_lds_bytes(g);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(std::make_tuple(dev, fn, lds));
+    const auto key = std::make_tuple(dev, fn, g.E, g.n, g.m);
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)BPL_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const uint32_t r = (uint32_t)per_cu * device_cu_count();
-    cache[std::make_tuple(dev, fn, lds)] = r;
-    return r;
+    const bool mixed = !(dv == 3);
+    BpLdsShape best{0, 0, 0};
+    for (uint32_t copies = 0; copies <= 2; copies++) {
+        const size_t lds = bp_lds_words(g, copies, mixed) * 8;
+        if (lds > 160 * 1024) break;
+        int per_cu = 0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) break;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)BPL_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = copies == 0 ? 1 : 0;
+        const uint32_t wgs = (uint32_t)per_cu * device_cu_count();
+        if (wgs && wgs >= best.workgroups) best = BpLdsShape{copies, wgs, lds};
+    }
+    cache[key] = best;
+    return best;
 }
 
-uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv) { return bp_lds_resident(g, dc, dv); }
+uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv) { return bp_lds_shape(g, dc, dv).workgroups; }
 
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
     const bp_lds_fn k = bp_lds_kernel_for(dc, dv);
     if (!k || a.post_out || a.chk_out) return hipErrorInvalidValue;
-    const size_t lds = bp_lds_bytes(g);
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const BpLdsShape sh = bp_lds_shape(g, dc, dv);
+    if (!sh.workgroups) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
     if (e != hipSuccess) return e;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, bp_lds_resident(g, dc, dv));
-    if (switches().debug) std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot, %u workgroups\n", lds, grid);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
+    if (switches().debug)
+        std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups\n", sh.lds, sh.copies, grid);
     g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : "bp_lds_kernel<3>";
-    hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), lds, st, g, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), sh.lds, st, g, a, sh.copies);
     return hipGetLastError();
 }
 
