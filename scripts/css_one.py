@@ -13,4 +13,5 @@ dec = CssDecoder(css, p, 100)
 dec.mc_run(p, 1, 0, 4096)
 cnt = dec.mc_run(p, 1, 0, shots)
 ms = ldpc_amd.last_kernel_ms()
-print("css shots", shots, "ms", ms, "shots/s %.3g" % (shots / ms * 1e3), "iters/shot", int(cnt[4]) / shots, "fail", int(cnt[1]))
+print("css shots", shots, "ms", ms, "shots/s %.3g" % (shots / ms * 1e3), "iters/shot", int(cnt[4]) / shots, "fail", int(cnt[1]),
+      "ran/shot", ldpc_amd.last_bp_executed_iterations() / shots)

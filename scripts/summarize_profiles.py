@@ -52,15 +52,17 @@ def bp(sub, name, kernel, edges, label):
     keep_stats(sub, name)
     k = summarize(os.path.join(src, sub), kernel)
     ln = log_line(sub, "iters")
+    # iters = what the counters report (the reference's count); ran = iterations actually run (the LDS form ends
+    # periodic runs early): the bytes are priced on ran
     if name == "css":
-        m = re.search(r"shots (\d+) ms ([\d.]+) .* iters/shot ([\d.]+)", ln)
-        shots, ms, iters = int(m.group(1)), float(m.group(2)), float(m.group(3)) * int(m.group(1))
+        m = re.search(r"shots (\d+) ms ([\d.]+) .* iters/shot ([\d.]+) fail \d+ ran/shot ([\d.]+)", ln)
+        shots, ms, iters, ran = int(m.group(1)), float(m.group(2)), float(m.group(3)) * int(m.group(1)), float(m.group(4)) * int(m.group(1))
     else:
         kv = dict(zip(ln.split()[2::2], ln.split()[3::2]))
-        shots, ms, iters = int(kv["shots"]), float(kv["kernel_ms"]), float(kv["iters"])
-    alg = iters * 32 * edges
+        shots, ms, iters, ran = int(kv["shots"]), float(kv["kernel_ms"]), float(kv["iters"]), float(kv["ran"])
+    alg = ran * 32 * edges
     d = {
-        "command": "scripts/profile_round.sh -> scripts/pmc_run.sh " + label, "kernel": kernel, "shots": shots, "shot_iterations": iters,
+        "command": "scripts/profile_round.sh -> scripts/pmc_run.sh " + label, "kernel": kernel, "shots": shots, "shot_iterations_reported": iters, "shot_iterations_run": ran,
         "call_ms_hip_events_under_kernel_trace": ms, "kernel_time": k["time"],
         "algorithmic_bytes": alg, "algorithmic_GBs_whole_call": alg / ms / 1e6,
         "algorithmic_GBs_in_kernel": alg / k["time"]["total_ms"] / 1e6,
@@ -76,6 +78,6 @@ def bp(sub, name, kernel, edges, label):
 
 bp("bp", "bp", "bp_kernel<6, 3>", 30000, "python3 scripts/bp_one.py c2 8388608 0.02")
 bp("c5", "bp_c5", "bps_iterate", 3000000, "python3 scripts/bp_one.py c5 70656 0.02")
-bp("css", "css", "bp_kernel<7, -4>", 2100, "python3 scripts/css_one.py 8388608")
-bp("c1", "bp_c1", "bp_kernel<4, 3>", 3600, "python3 scripts/bp_one.py c1 4194304 0.02")
+bp("css", "css", "bp_lds_kernel<7, -4>", 2100, "python3 scripts/css_one.py 8388608")
+bp("c1", "bp_c1", "bp_lds_kernel<4, 3>", 3600, "python3 scripts/bp_one.py c1 4194304 0.02")
 print(json.dumps(out, indent=1))
