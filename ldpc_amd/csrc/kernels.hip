@@ -2196,6 +2196,8 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 // converge holds one workgroup, not a 64-slot group.  Posterior / message outputs are left to the other forms.
 // ---------------------------------------------------------------------------
 constexpr uint32_t BPL_THREADS = 320;   // 5 waves: 300 / 900 checks and 625 / 1200 bits (C3, C1) leave few lanes idle
+// first-iteration table (see the kernel): bit messages [degree 1..4][sign pattern][edge] and posteriors [degree 0..4][pattern]
+constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #ifndef BPL_WAVES_PER_SIMD
 #define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
 #endif
@@ -2207,7 +2209,7 @@ __host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t co
 {
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
     const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0);
-    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + (u16s + 3) / 4;
+    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + BPL_TABLE_WORDS + (u16s + 3) / 4;
 }
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
@@ -2222,7 +2224,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     uint32_t *q = (uint32_t *)(rw + Wm);
     uint32_t *sh_flag = q + 65;   // (the gap table's 66th word)
     unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 33);
-    uint16_t *tedge = (uint16_t *)(sh_queue + 1), *tptr = tedge + E, *hidx = tptr + (DV > 0 ? 0 : n + 1);
+    double *tab_t = (double *)(sh_queue + 1), *tab_p = tab_t + 4 * 16 * 4;
+    uint16_t *tedge = (uint16_t *)(tab_p + 5 * 16), *tptr = tedge + E, *hidx = tptr + (DV > 0 ? 0 : n + 1);
     const bool c_edges = copies >= 1, c_checks = copies >= 2;
     auto edge_of = [&](uint32_t k) -> uint32_t { return c_edges ? (uint32_t)tedge[k] : g.t_edge[k]; };
     auto first_edge = [&](uint32_t b) -> uint32_t { return c_edges ? (uint32_t)tptr[b] : g.t_ptr[b]; };
@@ -2239,6 +2242,35 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         for (uint32_t e = tid; e < E; e += NT) hidx[e] = (uint16_t)g.h_idx[e];
     const double prior = a.prior, t_prior = bp_tanh_half(prior);
     const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
+    // The first iteration of every shot starts from the same messages (the prior, :60-68), so update_checks gives one
+    // value v0 for every edge, negated where the check's syndrome bit is set (:160-162), and what update_bits makes of
+    // a bit's d <= 4 incoming +-v0 depends on their signs alone: 2^d cases.  They are computed once per workgroup, by
+    // the functions and in the orders of the general path (so bit for bit what it would compute), and the first
+    // iteration of a shot is then a table look-up per edge.  (DV == 0, bits of any degree: general path throughout.)
+    constexpr bool FIRST_BY_TABLE = DV != 0;
+    if (FIRST_BY_TABLE) {
+        double x[DC], out[DC];
+#pragma unroll
+        for (int j = 0; j < DC; j++) x[j] = t_prior;
+        bp_check_row<DC>(x, 0u, out);
+        const double v0 = out[0];
+        if (tid < 5 * 16) {
+            const uint32_t d = tid >> 4, pat = tid & 15;
+            double v[4], sum = 0.0, post = prior;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[k] = (pat >> k) & 1u ? -v0 : v0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++)
+                if (k < d) {
+                    sum += v[k];
+                    post += v[k];
+                }
+            tab_p[d * 16 + pat] = post;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++)
+                if (k < d) tab_t[((d - 1) * 16 + pat) * 4 + k] = bp_tanh_half(sum - v[k] + prior);
+        }
+    }
     uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0, c_ran = 0;   // thread 0
     // A run that never converges ends up repeating itself: on the degenerate quantum codes every such run alternates
     // between two states from about its tenth iteration on.  The update is a function of the bit messages alone, so
@@ -2271,7 +2303,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             ew[w] = x;
             dw[w] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
         }
-        for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
+        if (!FIRST_BY_TABLE)
+            for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
         __syncthreads();
         // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision, 64 checks
         // per wave and trip: a ballot packs the parities.  The bit update keeps the residual current from then on.
@@ -2321,8 +2354,9 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             const bool save = saved != nullptr && t >= 6 && !(t & 1u) && !last_one;
             compared = save && t >= 8;
             if (compared && tid == 0) *sh_flag = 0;
+            const bool by_table = FIRST_BY_TABLE && iter == 0;
             // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
-            for (uint32_t c = tid; c < m; c += NT) {
+            for (uint32_t c = tid; c < m && !by_table; c += NT) {
                 double x[DC], out[DC];
 #pragma unroll
                 for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
@@ -2341,7 +2375,19 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     constexpr uint32_t RD = DV > 0 ? (uint32_t)DV : DV < 0 ? (uint32_t)(-DV) : REG_DEG;
                     const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), dv = DV > 0 ? (uint32_t)DV : first_edge(b + 1) - k0;
                     double sum = 0.0, post = prior;
-                    if (DV != 0 || dv <= RD) {
+                    if (by_table) {
+                        uint32_t pat = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) {
+                                const uint32_t c = g.t_idx[k0 + k];
+                                pat |= ((sw32[c >> 5] >> (c & 31)) & 1u) << k;
+                            }
+#pragma unroll
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) msg[edge_of(k0 + k)] = tab_t[((dv - 1) * 16 + pat) * 4 + k];
+                        post = tab_p[dv * 16 + pat];
+                    } else if (DV != 0 || dv <= RD) {
                         uint32_t ed[RD];
                         double v[RD];
 #pragma unroll
@@ -2392,7 +2438,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 if (compared && __ballot(differs) && lane == 0) *sh_flag = 1;
             }
             iter++;
-            ran++;
+            if (!by_table) ran++;   // (iterations of message arithmetic: what rooflines are priced on)
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
         const bool det = !conv;

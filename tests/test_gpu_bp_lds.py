@@ -148,7 +148,10 @@ def test_lds_cuts_periodic_runs_short_and_changes_nothing(monkeypatch, max_iter)
     monkeypatch.delenv("LDPC_HIP_BP_PATH")
     assert (res["lds"][0] == res["persistent"][0]).all()
     assert res["persistent"][1] == res["persistent"][0][CNT_WORK]
+    # (the first iteration of a shot is served from a table and not counted as run; nothing else is skipped at 9)
+    cnt = res["lds"][0]
+    iterated = shots - int((out["lds"][1] == 0).sum())
     if max_iter >= 30:
-        assert res["lds"][1] < res["lds"][0][CNT_WORK]
+        assert res["lds"][1] < cnt[CNT_WORK] - iterated
     else:
-        assert res["lds"][1] == res["lds"][0][CNT_WORK]
+        assert res["lds"][1] == cnt[CNT_WORK] - iterated
