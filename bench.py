@@ -86,15 +86,21 @@ def replayed_ratio(path):
         return None
 
 
-def bp_roofline(alg_bytes, ms, pmc, kernel=""):
-    """alg_bytes: 32 * E per shot-iteration ACTUALLY RUN (ldpc_last_bp_executed_iterations: the LDS form ends a run that
-    is found to repeat with period two early, and those skipped iterations are not priced)."""
+def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None):
+    """alg_bytes: 32 * E per shot-iteration of message arithmetic ACTUALLY RUN (ldpc_last_bp_executed_iterations: the LDS
+    form serves a shot's first iteration from a table and ends a run that is found to repeat with period two early;
+    neither is priced).  reference_bytes: the same figure on the iterations the counters report, i.e. what
+    belief_propagation.rs:23-30 runs for these shots."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     if kernel.startswith("bp_lds_kernel"):
         # a shot's messages live in LDS: the algorithmic bytes never reach HBM, the figure is an equivalent rate
-        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "traffic_source": None, "note": "LDS-resident form: the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic, "
-                                                "HBM sees only the graph and the outputs; frac is that equivalent rate over the HBM peak"}
+        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+               "traffic_source": None, "note": "LDS-resident form: the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic, "
+                                               "HBM sees only the graph and the outputs; frac is that equivalent rate over the HBM peak, "
+                                               "on the iterations of message arithmetic that were run"}
+        if reference_bytes is not None:
+            out["frac_on_reference_iterations"] = reference_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return out
     ratio = replayed_ratio(pmc)
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": None if ratio is None else ratio * alg_bytes,
@@ -156,7 +162,8 @@ def bp_c1_line(shots=1 << 22):
             "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
             "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, "profiles/r02_bp_c1_pmc.json", kernel)}
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, "profiles/r02_bp_c1_pmc.json", kernel,
+                                    int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges())}
 
 
 def css_line(shots=1 << 23):
@@ -176,10 +183,11 @@ def css_line(shots=1 << 23):
                         "p=0.01, BP f64 max 100 iterations on each half, logical failure test, %d shots" % shots,
             "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot_both_halves": int(cnt[ldpc_amd.CNT_WORK]) / shots,
-            # runs that never converge (5 % of the shots) alternate between two states: found out exactly and ended early
+            # a shot's first iteration comes from a table; runs that never converge (5 % of the shots) alternate between two
+            # states, which is found out exactly and ends them early
             "iterations_run_per_shot_both_halves": ran / shots,
             "logical_failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * edges, ms, CSS_PMC, kernel)}
+            "roofline": bp_roofline(ran * 32 * edges, ms, CSS_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges)}
 
 
 def bp_c5_line(shots=70656):

@@ -561,7 +561,11 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // one shot 0.3 -> 0.07 ms, 16,384 shots 2.7-3x, 2^21 shots 1.24x / 1.40x / 1.09x; the CSS example's halves (check
     // degree 7, bits of degree 3 and 4) run level with bp_kernel at 2^22 shots and ahead below.  Posterior / message
     // outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and forbid it.
-    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out && (switches().bp_path == 3 || switches().bp_path == 0);
+    // (a code that leaves room for one workgroup per CU only, E >= 10^4, falls behind on calls of 10^6 shots: 0.83-0.9x)
+    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out &&
+                          (switches().bp_path == 3 ||
+                           (switches().bp_path == 0 && (r.n_shots <= (1ull << 18) ||
+                                                        bp_lds_workgroups(g, dec->reg_dc, dec->reg_dv) >= 2 * device_cu_count())));
     if (lds_form) {
         stream = false;
         groups = 0;
