@@ -155,3 +155,34 @@ def test_lds_cuts_periodic_runs_short_and_changes_nothing(monkeypatch, max_iter)
         assert res["lds"][1] < cnt[CNT_WORK] - iterated
     else:
         assert res["lds"][1] == cnt[CNT_WORK] - iterated
+
+
+def test_lds_regular_checks_irregular_bits(monkeypatch):
+    """Checks of degree 4, bits of degree 0 to beyond 8 (the bit update's general loop, no first-iteration table), NaN /
+    inf arithmetic at p = 0.08: all three forms bit for bit."""
+    rng = np.random.default_rng(17)
+    n, m = 150, 120
+    hot = rng.choice(n - 10, size=6, replace=False)          # a few bits in many checks; the last ten bits in none
+    rows = []
+    for c in range(m):
+        pool = np.concatenate([hot, rng.choice(n - 10, size=8, replace=False)]) if c % 2 == 0 else rng.choice(n - 10, size=12, replace=False)
+        rows.append(sorted(int(x) for x in rng.choice(np.unique(pool), size=4, replace=False)))
+    code = LinearCode.from_parity_check_matrix(n, rows)
+    degs = np.bincount(np.concatenate(rows), minlength=n)
+    assert degs.max() > 8 and degs.min() == 0
+    shots = 400
+    words = np.stack([orc.sample_bsc_words(5, i, 0.08, n) for i in range(shots)]).reshape(shots, nwords(n))
+
+    def run():
+        dec = BpDecoder(code, 0.08, 20)
+        do = dev_u64(words.shape)
+        dec.decode_batch(shots, to_dev_u64(words), do)
+        return (host_u64(do),)
+
+    out = _forms(monkeypatch, run)
+    assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"])
+    # max_iterations = 0: nothing is updated, the first decision (all zeros at a positive prior) comes back
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "lds")
+    do = dev_u64(words.shape)
+    BpDecoder(code, 0.08, 0).decode_batch(shots, to_dev_u64(words), do)
+    assert (host_u64(do) == words).all()
