@@ -2280,12 +2280,16 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     // `saved` (global, this workgroup's) and compare with what is there; a periodic run takes at most one more
     // iteration and reports max_iter.  Results and counters are those of the full run (tests/test_gpu_bp_lds.py).
     unsigned long long *saved = a.msg ? (unsigned long long *)a.msg + (size_t)blockIdx.x * E : nullptr;
+    // (the index of the next shot is asked for while the current one is worked: the queue's round trip is off the path)
+    unsigned long long next_i = 0;
+    if (tid == 0) next_i = atomicAdd(a.queue, 1ull);
     for (;;) {
         __syncthreads();
-        if (tid == 0) *sh_queue = atomicAdd(a.queue, 1ull);
+        if (tid == 0) *sh_queue = next_i;
         __syncthreads();
         const uint64_t myi = *sh_queue;
         if (myi >= a.n_shots) break;
+        bool asked = false;   // (thread 0: the next index is asked for once this shot's global loads are behind it)
         const uint64_t shot = a.first_shot + myi;
         // ---- the shot's error word (or the caller's), decision words, messages = the prior (:60-68)
         for (uint32_t w = tid; w < Wn; w += NT) {
@@ -2439,8 +2443,13 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             }
             iter++;
             if (!by_table) ran++;   // (iterations of message arithmetic: what rooflines are priced on)
+            if (tid == 0 && !asked) {
+                next_i = atomicAdd(a.queue, 1ull);
+                asked = true;
+            }
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
+        if (tid == 0 && !asked) next_i = atomicAdd(a.queue, 1ull);
         const bool det = !conv;
         bool fail = false;
         if (a.test != TEST_NONE) {
@@ -2450,13 +2459,19 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             uint32_t f = 0;
             if (a.test == TEST_RESIDUAL) {
                 for (uint32_t w = tid; w < Wn; w += NT) f |= (ew[w] ^ dw[w]) != 0 ? 1u : 0u;
-            } else {
-                for (uint32_t r = tid; r < a.l_rows; r += NT) {
+            } else if (!det) {   // (a run that did not converge has failed already, css.rs / css_decoding.rs:18)
+                // eight lanes per logical generator: its entries come in a few strided loads instead of one long chain
+                for (uint32_t r0 = 0; r0 < a.l_rows; r0 += NT / 8) {
+                    const uint32_t r = r0 + (tid >> 3);
                     uint32_t par = 0;
-                    for (uint32_t k = a.l_ptr[r]; k < a.l_ptr[r + 1]; k++) {
-                        const uint32_t b = a.l_idx[k];
-                        par ^= ((ew32[b >> 5] ^ dw32[b >> 5]) >> (b & 31)) & 1u;
-                    }
+                    if (r < a.l_rows)
+                        for (uint32_t k = a.l_ptr[r] + (tid & 7u); k < a.l_ptr[r + 1]; k += 8) {
+                            const uint32_t b = a.l_idx[k];
+                            par ^= ((ew32[b >> 5] ^ dw32[b >> 5]) >> (b & 31)) & 1u;
+                        }
+                    par ^= (uint32_t)__shfl_xor((int)par, 1);
+                    par ^= (uint32_t)__shfl_xor((int)par, 2);
+                    par ^= (uint32_t)__shfl_xor((int)par, 4);
                     f |= par;
                 }
             }
