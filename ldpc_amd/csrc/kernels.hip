@@ -1620,11 +1620,12 @@ constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // outgoing check messages, flip = 0x80000000 when the check's syndrome bit is set (the reference multiplies by
 // -1.0, :160-162).  The edges are worked in batches of HB: enough independent chains to keep the pipeline busy
 // next to the other waves of the SIMD, few enough to stay inside 128 registers.
-template <int DC> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
+// (HBSEL: batch size; 0 = the sizes measured best for bp_kernel's 128 registers)
+template <int DC, int HBSEL = 0> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
 {
     // (measured: degree 6 in two batches of 3 -- one batch of 6 is no faster, 2 + 2 + 2 is 1 % slower; degree 7 as
     // 4 + 3 -- 6 % faster on the CSS example than 3 + 3 + 1, 2 % faster than one batch of 7)
-    constexpr int HB = DC <= 3 ? DC : DC == 4 ? 2 : DC == 7 ? 4 : 3;
+    constexpr int HB = HBSEL > 0 ? (HBSEL < DC ? HBSEL : DC) : DC <= 3 ? DC : DC == 4 ? 2 : DC == 7 ? 4 : 3;
     double prod = 1.0;
 #pragma unroll
     for (int j = 0; j < DC; j++) prod *= t[j];
@@ -2198,6 +2199,9 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 constexpr uint32_t BPL_THREADS = 320;   // 5 waves: 300 / 900 checks and 625 / 1200 bits (C3, C1) leave few lanes idle
 // first-iteration table (see the kernel): bit messages [degree 1..4][sign pattern][edge] and posteriors [degree 0..4][pattern]
 constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
+#ifndef BPL_CHECK_BATCH
+#define BPL_CHECK_BATCH 0                // bp_kernel's batch sizes (batches of 2 spill less at 72 registers and measured slower: CSS 161 -> 216 ms)
+#endif
 #ifndef BPL_WAVES_PER_SIMD
 #define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
 #endif
@@ -2252,7 +2256,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         double x[DC], out[DC];
 #pragma unroll
         for (int j = 0; j < DC; j++) x[j] = t_prior;
-        bp_check_row<DC>(x, 0u, out);
+        bp_check_row<DC, BPL_CHECK_BATCH>(x, 0u, out);
         const double v0 = out[0];
         if (tid < 5 * 16) {
             const uint32_t d = tid >> 4, pat = tid & 15;
@@ -2365,7 +2369,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
 #pragma unroll
                 for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
                 const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
-                bp_check_row<DC>(x, sbit ? 0x80000000u : 0u, out);
+                bp_check_row<DC, BPL_CHECK_BATCH>(x, sbit ? 0x80000000u : 0u, out);
 #pragma unroll
                 for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
             }
