@@ -2251,8 +2251,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     // a bit's d <= 4 incoming +-v0 depends on their signs alone: 2^d cases.  They are computed once per workgroup, by
     // the functions and in the orders of the general path (so bit for bit what it would compute), and the first
     // iteration of a shot is then a table look-up per edge.  (DV == 0, bits of any degree: general path throughout.)
-    constexpr bool FIRST_BY_TABLE = DV != 0;
-    if (FIRST_BY_TABLE) {
+    constexpr bool FIRST_BY_TABLE = DV != 0 && DC > 0;
+    if constexpr (FIRST_BY_TABLE) {
         double x[DC], out[DC];
 #pragma unroll
         for (int j = 0; j < DC; j++) x[j] = t_prior;
@@ -2322,13 +2322,14 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             if (c < m) {
                 if (a.source == SRC_SYNDROMES) par = (uint32_t)(a.synd_in[myi * Wm + (c >> 6)] >> (c & 63)) & 1u;
                 else {
-#pragma unroll
-                    for (int j = 0; j < DC; j++) {
-                        const uint32_t b = bit_of_check(c * (uint32_t)DC + j);
+                    const uint32_t e0 = DC > 0 ? c * (uint32_t)DC : g.h_ptr[c], e1 = DC > 0 ? e0 + (uint32_t)DC : g.h_ptr[c + 1];
+                    for (uint32_t e = e0; e < e1; e++) {
+                        const uint32_t b = bit_of_check(e);
                         par ^= (ew32[b >> 5] >> (b & 31)) & 1u;
                     }
                 }
-                rpar = par ^ (init ? (uint32_t)(DC & 1) : 0u);
+                const uint32_t dc = DC > 0 ? (uint32_t)DC : g.h_ptr[c + 1] - g.h_ptr[c];
+                rpar = par ^ (init ? dc & 1u : 0u);
             }
             const uint64_t mask = __ballot(par != 0), rmask = __ballot(rpar != 0);
             if (lane == 0) {
@@ -2365,13 +2366,43 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             const bool by_table = FIRST_BY_TABLE && iter == 0;
             // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
             for (uint32_t c = tid; c < m && !by_table; c += NT) {
-                double x[DC], out[DC];
-#pragma unroll
-                for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
                 const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
-                bp_check_row<DC, BPL_CHECK_BATCH>(x, sbit ? 0x80000000u : 0u, out);
+                if constexpr (DC > 0) {
+                    double x[DC], out[DC];
 #pragma unroll
-                for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
+                    for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
+                    bp_check_row<DC, BPL_CHECK_BATCH>(x, sbit ? 0x80000000u : 0u, out);
+#pragma unroll
+                    for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
+                } else {
+                    // checks of any degree: bp_kernel's general row, operation for operation
+                    const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
+                    if (dc <= REG_DEG) {
+                        double t[REG_DEG];
+                        double prod = 1.0;
+#pragma unroll
+                        for (uint32_t j = 0; j < REG_DEG; j++)
+                            if (j < dc) {
+                                t[j] = msg[e0 + j];
+                                prod *= t[j];
+                            }
+#pragma unroll
+                        for (uint32_t j = 0; j < REG_DEG; j++)
+                            if (j < dc) {
+                                double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, t[j]));
+                                if (sbit) v *= -1.0;
+                                msg[e0 + j] = v;
+                            }
+                    } else {
+                        double prod = 1.0;
+                        for (uint32_t j = 0; j < dc; j++) prod *= msg[e0 + j];
+                        for (uint32_t j = 0; j < dc; j++) {
+                            double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, msg[e0 + j]));
+                            if (sbit) v *= -1.0;
+                            msg[e0 + j] = v;
+                        }
+                    }
+                }
             }
             __syncthreads();
             // ---- update_bits (:168-180) + hard decision (:100-113), in place: check messages in, tanh((sum - own + prior) / 2)
@@ -3341,7 +3372,7 @@ static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
     case 4: return v == 3 ? bp_lds_kernel<4, 3> : v == -4 ? bp_lds_kernel<4, -4> : bp_lds_kernel<4, 0>;
     case 6: return v == 3 ? bp_lds_kernel<6, 3> : v == -4 ? bp_lds_kernel<6, -4> : bp_lds_kernel<6, 0>;
     case 7: return v == 3 ? bp_lds_kernel<7, 3> : v == -4 ? bp_lds_kernel<7, -4> : bp_lds_kernel<7, 0>;
-    default: return nullptr;
+    default: return v == -4 || v == 3 ? bp_lds_kernel<0, -4> : bp_lds_kernel<0, 0>;   // checks of any degree
     }
 }
 
@@ -3399,7 +3430,7 @@ hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, 
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
     if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups\n", sh.lds, sh.copies, grid);
-    g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : "bp_lds_kernel<3>";
+    g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : dc == 3 ? "bp_lds_kernel<3>" : "bp_lds_kernel<0>";
     hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), sh.lds, st, g, a, sh.copies);
     return hipGetLastError();
 }

@@ -186,3 +186,27 @@ def test_lds_regular_checks_irregular_bits(monkeypatch):
     do = dev_u64(words.shape)
     BpDecoder(code, 0.08, 0).decode_batch(shots, to_dev_u64(words), do)
     assert (host_u64(do) == words).all()
+
+
+def test_lds_checks_of_any_degree(monkeypatch):
+    """Irregular rows (degree 1 to 12, empty rows, degree-0 bits), the repetition code (check degree 2) and the
+    Hamming code: the LDS form's general check row against the other forms, bit for bit, at p = 0.08 (NaN / inf
+    arithmetic on the shots that do not converge)."""
+    from tests.gpu_util import random_sparse_rows
+    rng = np.random.default_rng(9)
+    codes = [LinearCode.from_parity_check_matrix(n, random_sparse_rows(rng, n, m, maxdeg))
+             for (n, m, maxdeg) in [(7, 3, 4), (65, 40, 6), (130, 90, 12), (300, 200, 5)]]
+    codes += [LinearCode.repetition_code(9), LinearCode.hamming_code()]
+    for code in codes:
+        n, shots = code.len(), 200
+        words = np.stack([orc.sample_bsc_words(5, i, 0.08, n) for i in range(shots)]).reshape(shots, max(nwords(n), 1))
+
+        def run():
+            dec = BpDecoder(code, 0.08, 12)
+            do = dev_u64(words.shape)
+            dec.decode_batch(shots, to_dev_u64(words), do)
+            cnt = dec.mc_run(0.08, 4, 0, 500)
+            return host_u64(do), cnt
+
+        out = _forms(monkeypatch, run)
+        assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"]), n
