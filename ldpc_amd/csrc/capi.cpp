@@ -159,7 +159,7 @@ struct ldpc_code {
     mutable std::mutex mu;
     mutable bool uploaded = false;
     mutable int device = -1;   // the GPU that holds the graph (and the owning decoder's buffers)
-    mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge;
+    mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge, d_tpack;
     mutable DeviceGraph dg{};
     // staging for the single-vector entry points (kept across calls: a trait-level call is one shot, and an
     // allocation and a free per call would cost more than its kernel); io_mu is held for the whole call
@@ -198,6 +198,13 @@ struct ldpc_code {
         HIP_TRY(up(d_tptr, t.ptr));
         HIP_TRY(up(d_tidx, t.idx));
         HIP_TRY(up(d_tedge, tedge));
+        dg.t_pack = nullptr;
+        if (t.nnz() && t.nnz() < 65536 && h.nrows() < 65536) {   // (small codes: bp_lds_kernel reads edge and check of a slot as one word)
+            std::vector<uint32_t> pack(t.nnz());
+            for (size_t k = 0; k < pack.size(); k++) pack[k] = tedge[k] | (t.idx[k] << 16);
+            HIP_TRY(up(d_tpack, pack));
+            dg.t_pack = d_tpack.as<uint32_t>();
+        }
         dg.n = h.ncols;
         dg.m = h.nrows();
         dg.E = h.nnz();
@@ -602,6 +609,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     a.executed = dec->counters.as<unsigned long long>() + LDPC_COUNTERS + 2;
     if (r.logicals) {
         a.l_rows = r.logicals->dg.m;
+        a.l_nnz = r.logicals->dg.E;
         a.l_ptr = r.logicals->dg.h_ptr;
         a.l_idx = r.logicals->dg.h_idx;
     }

@@ -20,6 +20,7 @@ struct DeviceGraph {
     const uint32_t *t_ptr;  // [n+1]  bit   -> first slot of bit_adjacencies
     const uint32_t *t_idx;  // [E]    slot  -> check (ascending inside a bit)
     const uint32_t *t_edge; // [E]    slot  -> edge index in check-major order
+    const uint32_t *t_pack; // [E]    slot  -> edge | check << 16 (one load for both; null unless E and m are below 65536)
 };
 
 // Geometric gap table of a channel: P(gap >= j) = q[j] / 2^32, j = 1..64.

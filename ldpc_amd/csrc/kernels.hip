@@ -2208,13 +2208,21 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 
 // LDS of a workgroup, in u64 words: messages, error / decision / syndrome / residual words, gap table, queue slot,
 // then copies of the graph as u16 when they do not cost a resident workgroup (copies >= 1: bit -> edges, and bit ->
-// first edge for codes with bits of mixed degree; 2: check -> bits as well)
-__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t copies, bool mixed_bits)
+// first edge for codes with bits of mixed degree; 2: bit -> checks as well; 3: the logical generators' rows of the CSS test)
+__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t copies, bool mixed_bits, uint32_t l_rows, uint32_t l_nnz)
 {
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0);
-    return (size_t)g.E + 2 * Wn + 2 * Wm + 33 + 1 + BPL_TABLE_WORDS + (u16s + 3) / 4;
+    const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0) +
+                        (copies >= 3 ? (size_t)l_rows + 1 + l_nnz : 0);
+    return (size_t)g.E + 2 * Wn + 2 * Wm + 34 + 2 + BPL_TABLE_WORDS + (u16s + 3) / 4;
 }
+
+// (diagnostic build, -DBPL_PROF: wave 0 of workgroup 0 prints the cycles it spent in each phase)
+#ifdef BPL_PROF
+#define BPL_STAMP(k) do { const uint64_t tn_ = __builtin_readcyclecounter(); prof[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define BPL_STAMP(k) do { } while (0)
+#endif
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
 template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
@@ -2226,24 +2234,32 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     double *msg = (double *)lds;
     uint64_t *ew = lds + E, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
     uint32_t *q = (uint32_t *)(rw + Wm);
-    uint32_t *sh_flag = q + 65;   // (the gap table's 66th word)
-    unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 33);
-    double *tab_t = (double *)(sh_queue + 1), *tab_p = tab_t + 4 * 16 * 4;
-    uint16_t *tedge = (uint16_t *)(tab_p + 5 * 16), *tptr = tedge + E, *hidx = tptr + (DV > 0 ? 0 : n + 1);
-    const bool c_edges = copies >= 1, c_checks = copies >= 2;
-    auto edge_of = [&](uint32_t k) -> uint32_t { return c_edges ? (uint32_t)tedge[k] : g.t_edge[k]; };
+    uint32_t *sh_flag = q + 65, *sh_fail = q + 66;   // (the words after the gap table's 65)
+    unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 34);   // (two slots, taken in turn: one barrier per hand-over)
+    double *tab_t = (double *)(sh_queue + 2), *tab_p = tab_t + 4 * 16 * 4;
+    uint16_t *tedge = (uint16_t *)(tab_p + 5 * 16), *tptr = tedge + E, *tidx = tptr + (DV > 0 ? 0 : n + 1);
+    uint16_t *lptr = tidx + (copies >= 2 ? E : 0), *lidx = lptr + a.l_rows + 1;
+    const bool c_edges = copies >= 1, c_checks = copies >= 2, c_logicals = copies >= 3;
+    auto edge_of = [&](uint32_t k) -> uint32_t { return c_edges ? (uint32_t)tedge[k] : g.t_pack[k] & 0xFFFFu; };
     auto first_edge = [&](uint32_t b) -> uint32_t { return c_edges ? (uint32_t)tptr[b] : g.t_ptr[b]; };
-    auto bit_of_check = [&](uint32_t e) -> uint32_t { return c_checks ? (uint32_t)hidx[e] : g.h_idx[e]; };
-    uint32_t *dw32 = (uint32_t *)dw, *rw32 = (uint32_t *)rw;
-    const uint32_t *sw32 = (const uint32_t *)sw, *ew32 = (const uint32_t *)ew;
+    auto check_of = [&](uint32_t k) -> uint32_t { return c_checks ? (uint32_t)tidx[k] : g.t_pack[k] >> 16; };
+    auto slot_of = [&](uint32_t k) -> uint32_t {   // edge | check << 16
+        return c_checks ? (uint32_t)tedge[k] | ((uint32_t)tidx[k] << 16) : c_edges ? (uint32_t)tedge[k] | (g.t_pack[k] & 0xFFFF0000u) : g.t_pack[k];
+    };
+    uint32_t *dw32 = (uint32_t *)dw, *rw32 = (uint32_t *)rw, *sw32 = (uint32_t *)sw;
+    const uint32_t *ew32 = (const uint32_t *)ew;
     for (uint32_t i = tid; i < 65; i += NT) q[i] = a.gap.q[i];
     if (c_edges) {
-        for (uint32_t e = tid; e < E; e += NT) tedge[e] = (uint16_t)g.t_edge[e];
+        for (uint32_t e = tid; e < E; e += NT) tedge[e] = (uint16_t)g.t_pack[e];
         if (DV <= 0)
             for (uint32_t b = tid; b <= n; b += NT) tptr[b] = (uint16_t)g.t_ptr[b];
     }
     if (c_checks)
-        for (uint32_t e = tid; e < E; e += NT) hidx[e] = (uint16_t)g.h_idx[e];
+        for (uint32_t e = tid; e < E; e += NT) tidx[e] = (uint16_t)(g.t_pack[e] >> 16);
+    if (c_logicals) {
+        for (uint32_t r = tid; r <= a.l_rows; r += NT) lptr[r] = (uint16_t)a.l_ptr[r];
+        for (uint32_t k = tid; k < a.l_nnz; k += NT) lidx[k] = (uint16_t)a.l_idx[k];
+    }
     const double prior = a.prior, t_prior = bp_tanh_half(prior);
     const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
     // The first iteration of every shot starts from the same messages (the prior, :60-68), so update_checks gives one
@@ -2287,12 +2303,16 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     // (the index of the next shot is asked for while the current one is worked: the queue's round trip is off the path)
     unsigned long long next_i = 0;
     if (tid == 0) next_i = atomicAdd(a.queue, 1ull);
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) *sh_queue = next_i;
-        __syncthreads();
-        const uint64_t myi = *sh_queue;
+#ifdef BPL_PROF
+    uint64_t prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
+    for (uint32_t turn = 0;; turn ^= 1u) {
+        if (tid == 0) sh_queue[turn] = next_i;
+        __syncthreads();   // (also: the last shot's failure test has read its words, the tables and graph copies are written)
+        const uint64_t myi = sh_queue[turn];
         if (myi >= a.n_shots) break;
+        if (tid == 0) *sh_fail = 0;
+        BPL_STAMP(0);
         bool asked = false;   // (thread 0: the next index is asked for once this shot's global loads are behind it)
         const uint64_t shot = a.first_shot + myi;
         // ---- the shot's error word (or the caller's), decision words, messages = the prior (:60-68)
@@ -2311,34 +2331,43 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             ew[w] = x;
             dw[w] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
         }
+        // (syndrome words: the caller's, or zero for the scatter below; the residual starts as syndrome ^ H * (decision
+        // before the first update), where H * (all ones) is the parity of the check's degree)
+        for (uint32_t w = tid; w < Wm; w += NT) {
+            const uint32_t nb = bits_in_word(m, w);
+            const uint64_t valid = nb < 64 ? (1ull << nb) - 1 : ~0ull;
+            const uint64_t x = a.source == SRC_SYNDROMES ? a.synd_in[myi * Wm + w] & valid : 0ull;
+            sw[w] = x;
+            rw[w] = x ^ (init && DC > 0 && (DC & 1) ? valid : 0ull);
+        }
         if (!FIRST_BY_TABLE)
             for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
         __syncthreads();
-        // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision, 64 checks
-        // per wave and trip: a ballot packs the parities.  The bit update keeps the residual current from then on.
-        for (uint32_t c0 = wv * 64; c0 < m; c0 += NT) {
-            const uint32_t c = c0 + lane;
-            uint32_t par = 0, rpar = 0;
-            if (c < m) {
-                if (a.source == SRC_SYNDROMES) par = (uint32_t)(a.synd_in[myi * Wm + (c >> 6)] >> (c & 63)) & 1u;
-                else {
-                    const uint32_t e0 = DC > 0 ? c * (uint32_t)DC : g.h_ptr[c], e1 = DC > 0 ? e0 + (uint32_t)DC : g.h_ptr[c + 1];
-                    for (uint32_t e = e0; e < e1; e++) {
-                        const uint32_t b = bit_of_check(e);
-                        par ^= (ew32[b >> 5] >> (b & 31)) & 1u;
+        BPL_STAMP(1);
+        // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision: every set
+        // bit of the error toggles its checks (few bits are set: E gathers become weight * degree atomics in LDS).  The
+        // bit update keeps the residual current from then on.
+        if (a.source != SRC_SYNDROMES)
+            for (uint32_t b = tid; b < n; b += NT)
+                if ((ew32[b >> 5] >> (b & 31)) & 1u) {
+                    const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), k1 = DV > 0 ? k0 + (uint32_t)DV : first_edge(b + 1);
+                    for (uint32_t k = k0; k < k1; k++) {
+                        const uint32_t c = check_of(k);
+                        atomicXor(&sw32[c >> 5], 1u << (c & 31));
+                        atomicXor(&rw32[c >> 5], 1u << (c & 31));
                     }
                 }
-                const uint32_t dc = DC > 0 ? (uint32_t)DC : g.h_ptr[c + 1] - g.h_ptr[c];
-                rpar = par ^ (init ? dc & 1u : 0u);
-            }
-            const uint64_t mask = __ballot(par != 0), rmask = __ballot(rpar != 0);
-            if (lane == 0) {
-                sw[c0 >> 6] = mask;
-                rw[c0 >> 6] = rmask;
+        if (DC == 0 && init) {   // (checks of mixed degree and a negative prior: the degrees' parities, 64 checks per wave and trip)
+            __syncthreads();
+            for (uint32_t c0 = wv * 64; c0 < m; c0 += NT) {
+                const uint32_t c = c0 + lane;
+                const uint64_t odd = __ballot(c < m && ((g.h_ptr[c + 1] - g.h_ptr[c]) & 1u));
+                if (lane == 0) rw[c0 >> 6] ^= odd;
             }
         }
         uint32_t iter = 0, ran = 0;
         bool conv, compared = false, last_one = false;
+        BPL_STAMP(2);
         for (;;) {
             // ---- stop test (belief_propagation.rs:26-27): H * decision == syndrome, i.e. the residual is zero (every
             // wave reads all of it: no flag to share)
@@ -2353,6 +2382,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 periodic = *sh_flag == 0;
                 __syncthreads();
             }
+            BPL_STAMP(3);
             if (conv || iter >= a.max_iter) break;
             if (last_one || (periodic && !((a.max_iter - iter) & 1u))) {
                 iter = a.max_iter;   // the run would go on alternating between this state and the last one
@@ -2405,6 +2435,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 }
             }
             __syncthreads();
+            BPL_STAMP(4);
             // ---- update_bits (:168-180) + hard decision (:100-113), in place: check messages in, tanh((sum - own + prior) / 2)
             // out; 64 consecutive bits per wave and trip, so a ballot is the decision word
             for (uint32_t b0 = wv * 64; b0 < n; b0 += NT) {
@@ -2415,16 +2446,19 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), dv = DV > 0 ? (uint32_t)DV : first_edge(b + 1) - k0;
                     double sum = 0.0, post = prior;
                     if (by_table) {
-                        uint32_t pat = 0;
+                        uint32_t pat = 0, pk[RD];
+#pragma unroll
+                        for (uint32_t k = 0; k < RD; k++)
+                            if (DV > 0 || k < dv) pk[k] = slot_of(k0 + k);
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
                             if (DV > 0 || k < dv) {
-                                const uint32_t c = g.t_idx[k0 + k];
+                                const uint32_t c = pk[k] >> 16;
                                 pat |= ((sw32[c >> 5] >> (c & 31)) & 1u) << k;
                             }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) msg[edge_of(k0 + k)] = tab_t[((dv - 1) * 16 + pat) * 4 + k];
+                            if (DV > 0 || k < dv) msg[pk[k] & 0xFFFFu] = tab_t[((dv - 1) * 16 + pat) * 4 + k];
                         post = tab_p[dv * 16 + pat];
                     } else if (DV != 0 || dv <= RD) {
                         uint32_t ed[RD];
@@ -2459,13 +2493,14 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     changed = dec != (((dw32[b >> 5] >> (b & 31)) & 1u) != 0);
                     if (changed)   // (few bits after the first iteration)
                         for (uint32_t k = 0; k < dv; k++) {
-                            const uint32_t c = g.t_idx[k0 + k];
+                            const uint32_t c = check_of(k0 + k);
                             atomicXor(&rw32[c >> 5], 1u << (c & 31));
                         }
                 }
                 const uint64_t mask = __ballot(dec);
                 if (lane == 0) dw[b0 >> 6] = mask;
             }
+            BPL_STAMP(by_table ? 5 : 6);
             if (save) {   // (wave-uniform; only runs that are still going after five iterations come here)
                 __syncthreads();
                 bool differs = false;
@@ -2476,6 +2511,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 }
                 if (compared && __ballot(differs) && lane == 0) *sh_flag = 1;
             }
+            BPL_STAMP(7);
             iter++;
             if (!by_table) ran++;   // (iterations of message arithmetic: what rooflines are priced on)
             if (tid == 0 && !asked) {
@@ -2487,10 +2523,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         if (tid == 0 && !asked) next_i = atomicAdd(a.queue, 1ull);
         const bool det = !conv;
         bool fail = false;
-        if (a.test != TEST_NONE) {
-            __syncthreads();
-            if (tid == 0) *sh_flag = 0;
-            __syncthreads();
+        if (a.test != TEST_NONE) {   // (every wave left the loop behind its barrier: the words are final)
             uint32_t f = 0;
             if (a.test == TEST_RESIDUAL) {
                 for (uint32_t w = tid; w < Wn; w += NT) f |= (ew[w] ^ dw[w]) != 0 ? 1u : 0u;
@@ -2499,20 +2532,22 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 for (uint32_t r0 = 0; r0 < a.l_rows; r0 += NT / 8) {
                     const uint32_t r = r0 + (tid >> 3);
                     uint32_t par = 0;
-                    if (r < a.l_rows)
-                        for (uint32_t k = a.l_ptr[r] + (tid & 7u); k < a.l_ptr[r + 1]; k += 8) {
-                            const uint32_t b = a.l_idx[k];
+                    if (r < a.l_rows) {
+                        const uint32_t k1 = c_logicals ? (uint32_t)lptr[r + 1] : a.l_ptr[r + 1];
+                        for (uint32_t k = (c_logicals ? (uint32_t)lptr[r] : a.l_ptr[r]) + (tid & 7u); k < k1; k += 8) {
+                            const uint32_t b = c_logicals ? (uint32_t)lidx[k] : a.l_idx[k];
                             par ^= ((ew32[b >> 5] ^ dw32[b >> 5]) >> (b & 31)) & 1u;
                         }
+                    }
                     par ^= (uint32_t)__shfl_xor((int)par, 1);
                     par ^= (uint32_t)__shfl_xor((int)par, 2);
                     par ^= (uint32_t)__shfl_xor((int)par, 4);
                     f |= par;
                 }
             }
-            if (__ballot(f != 0) && lane == 0) *sh_flag = 1;
+            if (__ballot(f != 0) && lane == 0) *sh_fail = 1;
             __syncthreads();
-            fail = a.test == TEST_RESIDUAL ? *sh_flag != 0 : det || *sh_flag != 0;
+            fail = a.test == TEST_RESIDUAL ? *sh_fail != 0 : det || *sh_fail != 0;
         }
         if (a.corr_out)
             for (uint32_t w = tid; w < Wn; w += NT) a.corr_out[myi * Wn + w] = a.xor_input ? dw[w] ^ ew[w] : dw[w];
@@ -2521,7 +2556,15 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
             c_shots++; c_fail += fail; c_det += det; c_work += iter; c_ran += ran;
         }
+        BPL_STAMP(8);
     }
+#ifdef BPL_PROF
+    if (blockIdx.x == 0 && tid == 0 && c_shots)
+        printf("bp_lds phases, cycles per shot over %llu shots (%llu iterations by arithmetic): queue %.0f  words %.0f  syndrome %.0f  "
+               "stop %.0f  checks %.0f  bits(table) %.0f  bits %.0f  save/compare %.0f  harvest %.0f\n", (unsigned long long)c_shots,
+               (unsigned long long)c_ran, (double)prof[0] / c_shots, (double)prof[1] / c_shots, (double)prof[2] / c_shots, (double)prof[3] / c_shots,
+               (double)prof[4] / c_shots, (double)prof[5] / c_shots, (double)prof[6] / c_shots, (double)prof[7] / c_shots, (double)prof[8] / c_shots);
+#endif
     if (tid == 0 && a.executed && c_ran) atomicAdd(a.executed, (unsigned long long)c_ran);
     if (tid == 0 && a.counters) {
         if (c_shots) atomicAdd(&a.counters[CNT_SHOTS], (unsigned long long)c_shots);
@@ -3377,11 +3420,11 @@ static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
 }
 
 // smallest LDS footprint of a workgroup (no graph copies)
-size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g, 0, false) * 8; }
+size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g, 0, false, 0, 0) * 8; }
 
 bool bp_lds_serves(const DeviceGraph &g, int dc)
 {
-    return bp_lds_kernel_for(dc, 0) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && bp_lds_bytes(g) <= 150 * 1024;   // (u16 graph copies)
+    return bp_lds_kernel_for(dc, 0) != nullptr && g.E > 0 && g.E < 65536 && g.n < 65535 && g.t_pack && bp_lds_bytes(g) <= 150 * 1024;   // (16-bit graph entries)
 }
 
 // The launch shape of the LDS form for a code: as many graph copies in LDS as cost no resident workgroup (asked of the
@@ -3390,21 +3433,23 @@ struct BpLdsShape {
     uint32_t copies, workgroups;
     size_t lds;
 };
-static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv)
+static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_rows = 0, uint32_t l_nnz = 0)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, const void *, uint32_t, uint32_t, uint32_t>, BpLdsShape> cache;
+    static std::map<std::tuple<int, const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, BpLdsShape> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void *fn = (const void *)bp_lds_kernel_for(dc, dv);
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_tuple(dev, fn, g.E, g.n, g.m);
+    const auto key = std::make_tuple(dev, fn, g.E, g.n, g.m, l_rows, l_nnz);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const bool mixed = !(dv == 3);
     BpLdsShape best{0, 0, 0};
-    for (uint32_t copies = 0; copies <= 2; copies++) {
-        const size_t lds = bp_lds_words(g, copies, mixed) * 8;
+    // (the most workgroups, then the most copies; the logical rows only when there are some and u16 holds their offsets)
+    const uint32_t most = l_rows && l_nnz < 65536 ? 3 : 2;
+    for (uint32_t copies = 0; copies <= most; copies++) {
+        const size_t lds = bp_lds_words(g, copies, mixed, l_rows, l_nnz) * 8;
         if (lds > 160 * 1024) break;
         int per_cu = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) break;
@@ -3423,7 +3468,8 @@ hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, 
     if (!a.n_shots) return hipSuccess;
     const bp_lds_fn k = bp_lds_kernel_for(dc, dv);
     if (!k || a.post_out || a.chk_out) return hipErrorInvalidValue;
-    const BpLdsShape sh = bp_lds_shape(g, dc, dv);
+    const bool logical = a.test == TEST_LOGICAL && a.l_rows;
+    const BpLdsShape sh = bp_lds_shape(g, dc, dv, logical ? a.l_rows : 0, logical ? a.l_nnz : 0);
     if (!sh.workgroups) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
     if (e != hipSuccess) return e;

@@ -107,7 +107,7 @@ struct BpArgs {
     uint8_t *failed_out;        // [n_shots]     or null
     unsigned long long *counters;
     // logical test matrix (rows = logical generators), TEST_LOGICAL only
-    uint32_t l_rows;
+    uint32_t l_rows, l_nnz;
     const uint32_t *l_ptr, *l_idx;
     // workspace, one slice per shot group (64 shots)
     double *msg;                // [groups][2][E][64]
