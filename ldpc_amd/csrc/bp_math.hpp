@@ -13,6 +13,24 @@
 
 namespace ldpc {
 
+// A f64 constant whose low word is not zero needs a register pair (the hardware takes 32-bit literals only, which give
+// a double's high word).  Left to the compiler, the two dozen constants of the polynomials below are built once at the
+// top of the kernel and held in vector registers for its whole life, and where registers are short (bp_lds_kernel: 72)
+// they are spilled and come back from scratch memory inside the check and bit updates.  With SK (scalar constants)
+// BP_K(x) builds x where it is used instead: two scalar moves that cannot be hoisted (volatile), on the scalar unit's
+// own issue port.  bp_lds_kernel asks for it (CSS example 150 -> 128 ms); bp_kernel, with 128 registers, measured 6 %
+// slower with it and keeps the compiler's choice.  The values are the same either way.
+template <bool SK, unsigned long long BITS> __device__ inline double bp_k64()
+{
+    if constexpr (SK) {
+        unsigned int hi, lo;
+        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(hi), "=s"(lo) : "n"((unsigned int)(BITS >> 32)), "n"((unsigned int)BITS));
+        return __hiloint2double((int)hi, (int)lo);
+    } else
+        return __builtin_bit_cast(double, BITS);
+}
+#define BP_K(x) (::ldpc::bp_k64<SK, __builtin_bit_cast(unsigned long long, (double)(x))>())
+
 // a / b without the scaling and fix-up steps of the IEEE expansion (13-14 instructions): hardware
 // reciprocal (about 23 bits), one Newton step, quotient, one residual correction.  The result is the
 // correctly rounded quotient except in a vanishing fraction of near-tie cases (tests/test_gpu_bp_math.py)
@@ -52,27 +70,26 @@ __device__ inline double bp_div_prod(double prod, double t)
 // formulas give 1 - E = -(expm1 part) without cancellation, so one path serves every x.
 // Measured: <= 0.55 ulp for |x| >= 0.5, <= 0.64 ulp below (the uncompensated rounding of r^2 Q(r) shows
 // when r is near ln2/2), 96-100 % correctly rounded; glibc's tanh: <= 1.15 ulp, about 80 %.
-__device__ inline double bp_tanh_half(double x)
+template <bool SK = false> __device__ inline double bp_tanh_half(double x)
 {
     const double ax = fabs(x);
     const double a = ax > 64.0 ? 64.0 : ax;       // tanh(32) is 1.0 in f64 already; keeps 2^-k normal; NaN stays NaN
-    const double kn = rint(a * -1.4426950408889634074);   // -k
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double rh = -(kn * ln2_hi) - a;         // k ln2_hi - a, exact (Cody-Waite, Sterbenz)
-    const double rl = -(kn * ln2_lo);
+    const double kn = rint(a * BP_K(-1.4426950408889634074));   // -k
+    const double rh = -(kn * BP_K(6.93147180369123816490e-01)) - a;   // k ln2_hi - a, exact (Cody-Waite, Sterbenz)
+    const double rl = -(kn * BP_K(1.90821492927058770002e-10));      // k ln2_lo
     const double r = rh + rl;
     const double rc = (rh - r) + rl;              // r + rc = rh + rl
-    double q = 1.0 / 6227020800.0;                // 1/13!
-    q = fma(q, r, 1.0 / 479001600.0);
-    q = fma(q, r, 1.0 / 39916800.0);
-    q = fma(q, r, 1.0 / 3628800.0);
-    q = fma(q, r, 1.0 / 362880.0);
-    q = fma(q, r, 1.0 / 40320.0);
-    q = fma(q, r, 1.0 / 5040.0);
-    q = fma(q, r, 1.0 / 720.0);
-    q = fma(q, r, 1.0 / 120.0);
-    q = fma(q, r, 1.0 / 24.0);
-    q = fma(q, r, 1.0 / 6.0);
+    double q = BP_K(1.0 / 6227020800.0);          // 1/13!
+    q = fma(q, r, BP_K(1.0 / 479001600.0));
+    q = fma(q, r, BP_K(1.0 / 39916800.0));
+    q = fma(q, r, BP_K(1.0 / 3628800.0));
+    q = fma(q, r, BP_K(1.0 / 362880.0));
+    q = fma(q, r, BP_K(1.0 / 40320.0));
+    q = fma(q, r, BP_K(1.0 / 5040.0));
+    q = fma(q, r, BP_K(1.0 / 720.0));
+    q = fma(q, r, BP_K(1.0 / 120.0));
+    q = fma(q, r, BP_K(1.0 / 24.0));
+    q = fma(q, r, BP_K(1.0 / 6.0));
     q = fma(q, r, 0.5);
     const double r2q = (r * r) * q;               // e^r - 1 - r
     const double ph = r + r2q;
@@ -99,12 +116,8 @@ __device__ inline double bp_tanh_half(double x)
 // the rounding error of 1+x enters as the correction c), written branch-free for a 64-lane wave;
 // zeros, infinities, NaN and x <= -1 are patched in a block a wave enters only if one of its lanes
 // holds such an argument.
-__device__ inline double bp_log1p_main(double x)
+template <bool SK = false> __device__ inline double bp_log1p_main(double x)
 {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
-                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
-                 Lp7 = 1.479819860511658591e-01;
     const double u = 1.0 + x;
     int hu = __double2hiint(u);
     int k = (hu >> 20) - 1023;
@@ -120,16 +133,16 @@ __device__ inline double bp_log1p_main(double x)
     const double hfsq = 0.5 * f * f;
     const double s = bp_div_core(f, 2.0 + f);            // 2 + f in [1.70, 2.42], |f| < 0.42 (or 0)
     const double z = s * s;
-    double r = Lp7;
-    r = fma(r, z, Lp6);
-    r = fma(r, z, Lp5);
-    r = fma(r, z, Lp4);
-    r = fma(r, z, Lp3);
-    r = fma(r, z, Lp2);
-    r = fma(r, z, Lp1);
+    double r = BP_K(1.479819860511658591e-01);      // Lp7
+    r = fma(r, z, BP_K(1.531383769920937332e-01));
+    r = fma(r, z, BP_K(1.818357216161805012e-01));
+    r = fma(r, z, BP_K(2.222219843214978396e-01));
+    r = fma(r, z, BP_K(2.857142874366239149e-01));
+    r = fma(r, z, BP_K(3.999999999940941908e-01));
+    r = fma(r, z, BP_K(6.666666666666735130e-01));  // Lp1
     r = r * z;
     const double dk = (double)k;
-    return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + (dk * ln2_lo + c))) - f);
+    return dk * BP_K(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + r) + (dk * BP_K(1.90821492927058770002e-10) + c))) - f);   // ln2_hi, ln2_lo
 }
 
 // arguments bp_log1p_main does not serve: -inf, +-0, +inf (class mask 0x264) and x <= -1.  (A NaN comes out of
@@ -146,9 +159,9 @@ __device__ inline double bp_log1p_fix(double x, double res)
     return res;
 }
 
-__device__ inline double bp_log1p(double x)
+template <bool SK = false> __device__ inline double bp_log1p(double x)
 {
-    double res = bp_log1p_main(x);
+    double res = bp_log1p_main<SK>(x);
     if (__builtin_expect(__ballot(bp_log1p_is_special(x)) != 0, 0)) res = bp_log1p_fix(x, res);
     return res;
 }
@@ -164,6 +177,6 @@ __device__ inline double bp_atanh_arg(double x)
     return x == 1.0 ? __builtin_huge_val() : q;
 }
 
-__device__ inline double bp_ref_atanh(double x) { return 0.5 * bp_log1p(bp_atanh_arg(x)); }
+template <bool SK = false> __device__ inline double bp_ref_atanh(double x) { return 0.5 * bp_log1p<SK>(bp_atanh_arg(x)); }
 
 }  // namespace ldpc

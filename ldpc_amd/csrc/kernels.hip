@@ -1621,7 +1621,7 @@ constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // -1.0, :160-162).  The edges are worked in batches of HB: enough independent chains to keep the pipeline busy
 // next to the other waves of the SIMD, few enough to stay inside 128 registers.
 // (HBSEL: batch size; 0 = the sizes measured best for bp_kernel's 128 registers)
-template <int DC, int HBSEL = 0> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
+template <int DC, int HBSEL = 0, bool SK = false> __device__ inline void bp_check_row(const double (&t)[DC], uint32_t flip, double (&out)[DC])
 {
     // (measured: degree 6 in two batches of 3 -- one batch of 6 is no faster, 2 + 2 + 2 is 1 % slower; degree 7 as
     // 4 + 3 -- 6 % faster on the CSS example than 3 + 3 + 1, 2 % faster than one batch of 7)
@@ -1660,7 +1660,7 @@ template <int DC, int HBSEL = 0> __device__ inline void bp_check_row(const doubl
         for (int j = 0; j < HB; j++)
             if (h0 + j < DC) {
                 special |= bp_log1p_is_special(w[j]);
-                l[j] = bp_log1p_main(w[j]);
+                l[j] = bp_log1p_main<SK>(w[j]);
             }
         if (__builtin_expect(__ballot(special) != 0, 0)) {
 #pragma unroll
@@ -2214,7 +2214,7 @@ __host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t co
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
     const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0) +
                         (copies >= 3 ? (size_t)l_rows + 1 + l_nnz : 0);
-    return (size_t)g.E + 2 * Wn + 2 * Wm + 34 + 2 + BPL_TABLE_WORDS + (u16s + 3) / 4;
+    return (size_t)g.E + 2 * Wn + 2 * Wm + 34 + 2 + 5 + BPL_TABLE_WORDS + (u16s + 3) / 4;
 }
 
 // (diagnostic build, -DBPL_PROF: wave 0 of workgroup 0 prints the cycles it spent in each phase)
@@ -2236,7 +2236,9 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     uint32_t *q = (uint32_t *)(rw + Wm);
     uint32_t *sh_flag = q + 65, *sh_fail = q + 66;   // (the words after the gap table's 65)
     unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 34);   // (two slots, taken in turn: one barrier per hand-over)
-    double *tab_t = (double *)(sh_queue + 2), *tab_p = tab_t + 4 * 16 * 4;
+    // (thread 0's counters live in LDS, not in ten registers that every check row would have to keep or spill)
+    unsigned long long *cnt = sh_queue + 2;   // shots, failures, runs that did not converge, iterations, iterations of arithmetic
+    double *tab_t = (double *)(cnt + 5), *tab_p = tab_t + 4 * 16 * 4;
     uint16_t *tedge = (uint16_t *)(tab_p + 5 * 16), *tptr = tedge + E, *tidx = tptr + (DV > 0 ? 0 : n + 1);
     uint16_t *lptr = tidx + (copies >= 2 ? E : 0), *lidx = lptr + a.l_rows + 1;
     const bool c_edges = copies >= 1, c_checks = copies >= 2, c_logicals = copies >= 3;
@@ -2260,7 +2262,10 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         for (uint32_t r = tid; r <= a.l_rows; r += NT) lptr[r] = (uint16_t)a.l_ptr[r];
         for (uint32_t k = tid; k < a.l_nnz; k += NT) lidx[k] = (uint16_t)a.l_idx[k];
     }
-    const double prior = a.prior, t_prior = bp_tanh_half(prior);
+    const double prior = a.prior, t_prior_v = bp_tanh_half<true>(prior);
+    // (wave-uniform values are moved to scalar registers by hand where the compiler would hold them per lane)
+    const double t_prior = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t_prior_v)),
+                                            __builtin_amdgcn_readfirstlane(__double2loint(t_prior_v)));
     const bool init = prior < 0.0;   // decision before the first update: posterior = prior (belief_propagation.rs:100-113)
     // The first iteration of every shot starts from the same messages (the prior, :60-68), so update_checks gives one
     // value v0 for every edge, negated where the check's syndrome bit is set (:160-162), and what update_bits makes of
@@ -2272,7 +2277,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         double x[DC], out[DC];
 #pragma unroll
         for (int j = 0; j < DC; j++) x[j] = t_prior;
-        bp_check_row<DC, BPL_CHECK_BATCH>(x, 0u, out);
+        bp_check_row<DC, BPL_CHECK_BATCH, true>(x, 0u, out);
         const double v0 = out[0];
         if (tid < 5 * 16) {
             const uint32_t d = tid >> 4, pat = tid & 15;
@@ -2288,10 +2293,11 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             tab_p[d * 16 + pat] = post;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++)
-                if (k < d) tab_t[((d - 1) * 16 + pat) * 4 + k] = bp_tanh_half(sum - v[k] + prior);
+                if (k < d) tab_t[((d - 1) * 16 + pat) * 4 + k] = bp_tanh_half<true>(sum - v[k] + prior);
         }
     }
-    uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_work = 0, c_ran = 0;   // thread 0
+    if (tid == 0)
+        for (uint32_t i = 0; i < 5; i++) cnt[i] = 0;
     // A run that never converges ends up repeating itself: on the degenerate quantum codes every such run alternates
     // between two states from about its tenth iteration on.  The update is a function of the bit messages alone, so
     // once they equal, bit for bit, those of two iterations before, the run is periodic for good: its stop tests keep
@@ -2300,20 +2306,20 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
     // `saved` (global, this workgroup's) and compare with what is there; a periodic run takes at most one more
     // iteration and reports max_iter.  Results and counters are those of the full run (tests/test_gpu_bp_lds.py).
     unsigned long long *saved = a.msg ? (unsigned long long *)a.msg + (size_t)blockIdx.x * E : nullptr;
-    // (the index of the next shot is asked for while the current one is worked: the queue's round trip is off the path)
-    unsigned long long next_i = 0;
-    if (tid == 0) next_i = atomicAdd(a.queue, 1ull);
+    // (the index of the next shot is asked for at the start of the current one's first bit update and put in the
+    // other queue slot at its end: the queue's round trip is off the path and the answer is not kept across a check row)
+    if (tid == 0) sh_queue[0] = atomicAdd(a.queue, 1ull);
 #ifdef BPL_PROF
     uint64_t prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t turn = 0;; turn ^= 1u) {
-        if (tid == 0) sh_queue[turn] = next_i;
         __syncthreads();   // (also: the last shot's failure test has read its words, the tables and graph copies are written)
-        const uint64_t myi = sh_queue[turn];
+        const uint64_t myi_v = sh_queue[turn];
+        const uint64_t myi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(myi_v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)myi_v);
         if (myi >= a.n_shots) break;
         if (tid == 0) *sh_fail = 0;
         BPL_STAMP(0);
-        bool asked = false;   // (thread 0: the next index is asked for once this shot's global loads are behind it)
+        bool asked = false;
         const uint64_t shot = a.first_shot + myi;
         // ---- the shot's error word (or the caller's), decision words, messages = the prior (:60-68)
         for (uint32_t w = tid; w < Wn; w += NT) {
@@ -2401,7 +2407,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     double x[DC], out[DC];
 #pragma unroll
                     for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
-                    bp_check_row<DC, BPL_CHECK_BATCH>(x, sbit ? 0x80000000u : 0u, out);
+                    bp_check_row<DC, BPL_CHECK_BATCH, true>(x, sbit ? 0x80000000u : 0u, out);
 #pragma unroll
                     for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
                 } else {
@@ -2419,7 +2425,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
 #pragma unroll
                         for (uint32_t j = 0; j < REG_DEG; j++)
                             if (j < dc) {
-                                double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, t[j]));
+                                double v = 2.0 * bp_ref_atanh<true>(bp_div_prod(prod, t[j]));
                                 if (sbit) v *= -1.0;
                                 msg[e0 + j] = v;
                             }
@@ -2427,7 +2433,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         double prod = 1.0;
                         for (uint32_t j = 0; j < dc; j++) prod *= msg[e0 + j];
                         for (uint32_t j = 0; j < dc; j++) {
-                            double v = 2.0 * bp_ref_atanh(bp_div_prod(prod, msg[e0 + j]));
+                            double v = 2.0 * bp_ref_atanh<true>(bp_div_prod(prod, msg[e0 + j]));
                             if (sbit) v *= -1.0;
                             msg[e0 + j] = v;
                         }
@@ -2438,6 +2444,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             BPL_STAMP(4);
             // ---- update_bits (:168-180) + hard decision (:100-113), in place: check messages in, tanh((sum - own + prior) / 2)
             // out; 64 consecutive bits per wave and trip, so a ballot is the decision word
+            unsigned long long next_i = 0;
+            if (!asked && tid == 0) next_i = atomicAdd(a.queue, 1ull);
             for (uint32_t b0 = wv * 64; b0 < n; b0 += NT) {
                 const uint32_t b = b0 + lane;
                 bool dec = false, changed = false;
@@ -2477,7 +2485,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                             }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) msg[ed[k]] = bp_tanh_half(sum - v[k] + prior);
+                            if (DV > 0 || k < dv) msg[ed[k]] = bp_tanh_half<true>(sum - v[k] + prior);
                     } else {
                         for (uint32_t k = 0; k < dv; k++) {
                             const double vv = msg[edge_of(k0 + k)];
@@ -2486,7 +2494,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         }
                         for (uint32_t k = 0; k < dv; k++) {
                             const uint32_t e = edge_of(k0 + k);
-                            msg[e] = bp_tanh_half(sum - msg[e] + prior);
+                            msg[e] = bp_tanh_half<true>(sum - msg[e] + prior);
                         }
                     }
                     dec = post < 0.0;
@@ -2499,6 +2507,10 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 }
                 const uint64_t mask = __ballot(dec);
                 if (lane == 0) dw[b0 >> 6] = mask;
+            }
+            if (!asked) {
+                if (tid == 0) sh_queue[turn ^ 1u] = next_i;
+                asked = true;
             }
             BPL_STAMP(by_table ? 5 : 6);
             if (save) {   // (wave-uniform; only runs that are still going after five iterations come here)
@@ -2514,13 +2526,9 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             BPL_STAMP(7);
             iter++;
             if (!by_table) ran++;   // (iterations of message arithmetic: what rooflines are priced on)
-            if (tid == 0 && !asked) {
-                next_i = atomicAdd(a.queue, 1ull);
-                asked = true;
-            }
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
-        if (tid == 0 && !asked) next_i = atomicAdd(a.queue, 1ull);
+        if (tid == 0 && !asked) sh_queue[turn ^ 1u] = atomicAdd(a.queue, 1ull);   // (a shot that stopped before its first update)
         const bool det = !conv;
         bool fail = false;
         if (a.test != TEST_NONE) {   // (every wave left the loop behind its barrier: the words are final)
@@ -2546,7 +2554,9 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 }
             }
             if (__ballot(f != 0) && lane == 0) *sh_fail = 1;
+            BPL_STAMP(8);
             __syncthreads();
+            BPL_STAMP(9);
             fail = a.test == TEST_RESIDUAL ? *sh_fail != 0 : det || *sh_fail != 0;
         }
         if (a.corr_out)
@@ -2554,16 +2564,18 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         if (tid == 0) {
             if (a.iters_out) a.iters_out[myi] = iter;
             if (a.failed_out && fail) a.failed_out[myi] |= (uint8_t)a.fail_bit;
-            c_shots++; c_fail += fail; c_det += det; c_work += iter; c_ran += ran;
+            cnt[0]++; cnt[1] += fail; cnt[2] += det; cnt[3] += iter; cnt[4] += ran;
         }
         BPL_STAMP(8);
     }
+    const unsigned long long c_shots = tid == 0 ? cnt[0] : 0, c_fail = tid == 0 ? cnt[1] : 0, c_det = tid == 0 ? cnt[2] : 0,
+                             c_work = tid == 0 ? cnt[3] : 0, c_ran = tid == 0 ? cnt[4] : 0;
 #ifdef BPL_PROF
     if (blockIdx.x == 0 && tid == 0 && c_shots)
         printf("bp_lds phases, cycles per shot over %llu shots (%llu iterations by arithmetic): queue %.0f  words %.0f  syndrome %.0f  "
-               "stop %.0f  checks %.0f  bits(table) %.0f  bits %.0f  save/compare %.0f  harvest %.0f\n", (unsigned long long)c_shots,
+               "stop %.0f  checks %.0f  bits(table) %.0f  bits %.0f  save/compare %.0f  harvest %.0f (of which its barrier %.0f)\n", (unsigned long long)c_shots,
                (unsigned long long)c_ran, (double)prof[0] / c_shots, (double)prof[1] / c_shots, (double)prof[2] / c_shots, (double)prof[3] / c_shots,
-               (double)prof[4] / c_shots, (double)prof[5] / c_shots, (double)prof[6] / c_shots, (double)prof[7] / c_shots, (double)prof[8] / c_shots);
+               (double)prof[4] / c_shots, (double)prof[5] / c_shots, (double)prof[6] / c_shots, (double)prof[7] / c_shots, (double)(prof[8] + prof[9]) / c_shots, (double)prof[9] / c_shots);
 #endif
     if (tid == 0 && a.executed && c_ran) atomicAdd(a.executed, (unsigned long long)c_ran);
     if (tid == 0 && a.counters) {
