@@ -19,12 +19,16 @@ namespace ldpc {
 // they are spilled and come back from scratch memory inside the check and bit updates.  With SK (scalar constants)
 // BP_K(x) builds x where it is used instead: two scalar moves that cannot be hoisted (volatile), on the scalar unit's
 // own issue port.  bp_lds_kernel asks for it (CSS example 150 -> 128 ms); bp_kernel, with 128 registers, measured 6 %
-// slower with it and keeps the compiler's choice.  The values are the same either way.
+// slower with it and keeps the compiler's choice.  The values are the same either way.  (Tried on the CSS example and
+// C1, per 2^22 shots on one box, against 129 / 105.7 ms: one fixed register pair s[98:99] so that the pair always goes
+// into v_fma_f64 as it is, 141 / 104.8; a pair built by 64-bit scalar operations, 129.4 / 106.1 -- the scalar unit issues
+// one instruction per SIMD turn like the vector unit and becomes the busier one; log1p of a check row's batch with the
+// constants built once per batch, 149 / 105.9, more registers spilled.)
 template <bool SK, unsigned long long BITS> __device__ inline double bp_k64()
 {
     if constexpr (SK) {
         unsigned int hi, lo;
-        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(hi), "=s"(lo) : "n"((unsigned int)(BITS >> 32)), "n"((unsigned int)BITS));
+        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((unsigned int)BITS), "n"((unsigned int)(BITS >> 32)));
         return __hiloint2double((int)hi, (int)lo);
     } else
         return __builtin_bit_cast(double, BITS);
@@ -109,6 +113,85 @@ template <bool SK = false> __device__ inline double bp_tanh_half(double x)
     const double big = fma(rem, rd, q0);
     // tanh is odd: put x's sign back (keeps -0; a NaN stays a NaN)
     return copysign(big, x);
+}
+
+// bp_tanh_half of the first cnt of N values, statement by statement across the batch: every value goes through the
+// operations of bp_tanh_half in their order (the same results, bit for bit), and a constant of the polynomial is
+// built once per batch instead of once per value.
+template <int N, bool SK> __device__ inline void bp_tanh_half_n(const double (&x)[N], double (&out)[N], int cnt)
+{
+    double a[N], kn[N], rh[N], rl[N], r[N], rc[N], q[N];
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        if (j < cnt) {
+            const double ax = fabs(x[j]);
+            a[j] = ax > 64.0 ? 64.0 : ax;
+        }
+    {
+        const double c = BP_K(-1.4426950408889634074);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < cnt) kn[j] = rint(a[j] * c);
+    }
+    {
+        const double c = BP_K(6.93147180369123816490e-01);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < cnt) rh[j] = -(kn[j] * c) - a[j];
+    }
+    {
+        const double c = BP_K(1.90821492927058770002e-10);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < cnt) {
+                rl[j] = -(kn[j] * c);
+                r[j] = rh[j] + rl[j];
+                rc[j] = (rh[j] - r[j]) + rl[j];
+            }
+    }
+    {
+        const double c = BP_K(1.0 / 6227020800.0);
+#pragma unroll
+        for (int j = 0; j < N; j++)
+            if (j < cnt) q[j] = c;
+    }
+#define BP_TANH_STEP(K)                                   \
+    {                                                     \
+        const double c = BP_K(K);                         \
+        _Pragma("unroll") for (int j = 0; j < N; j++)     \
+            if (j < cnt) q[j] = fma(q[j], r[j], c);       \
+    }
+    BP_TANH_STEP(1.0 / 479001600.0)
+    BP_TANH_STEP(1.0 / 39916800.0)
+    BP_TANH_STEP(1.0 / 3628800.0)
+    BP_TANH_STEP(1.0 / 362880.0)
+    BP_TANH_STEP(1.0 / 40320.0)
+    BP_TANH_STEP(1.0 / 5040.0)
+    BP_TANH_STEP(1.0 / 720.0)
+    BP_TANH_STEP(1.0 / 120.0)
+    BP_TANH_STEP(1.0 / 24.0)
+    BP_TANH_STEP(1.0 / 6.0)
+#undef BP_TANH_STEP
+#pragma unroll
+    for (int j = 0; j < N; j++)
+        if (j < cnt) {
+            const double qq = fma(q[j], r[j], 0.5);
+            const double r2q = (r[j] * r[j]) * qq;
+            const double ph = r[j] + r2q;
+            const double pl = ((r[j] - ph) + r2q) + fma(rc[j], ph, rc[j]);
+            const double sh = 1.0 + ph;
+            const double sl = ((1.0 - sh) + ph) + pl;
+            const int k = (int)kn[j];
+            const double eh = ldexp(sh, k), el = ldexp(sl, k);
+            const double nh = 1.0 - eh, nl = ((1.0 - nh) - eh) - el;
+            const double dh = 1.0 + eh, dl = ((1.0 - dh) + eh) + el;
+            double rd = __builtin_amdgcn_rcp(dh);
+            rd = fma(fma(-dh, rd, 1.0), rd, rd);
+            const double q0 = nh * rd;
+            const double rem = fma(-q0, dh, nh) + (nl - q0 * dl);
+            const double big = fma(rem, rd, q0);
+            out[j] = copysign(big, x[j]);
+        }
 }
 
 // log1p(x), argument reduction and kernel polynomial of the classic fdlibm scheme

@@ -1613,6 +1613,10 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
 // iteration cap) is harvested and refilled from a device-wide shot queue.
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
+// (bp_lds_kernel's use of the scalar-constant forms of bp_math.hpp)
+#ifndef BPL_TANH_BATCH
+#define BPL_TANH_BATCH 4                // tanh of a bit's three or four messages: 1 = one by one, 2 = in pairs, else as one batch
+#endif                                  // (CSS example / C1 per 2^22 shots, one box: 129 / 105.7, 137 / 102.7, 127 / 101.9 ms)
 
 
 // update_checks for one check of degree DC (belief_propagation.rs:150-166): t = tanh(x/2) of the incoming bit
@@ -2470,13 +2474,15 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         post = tab_p[dv * 16 + pat];
                     } else if (DV != 0 || dv <= RD) {
                         uint32_t ed[RD];
-                        double v[RD];
+                        double v[RD], y[RD];
 #pragma unroll
-                        for (uint32_t k = 0; k < RD; k++)
+                        for (uint32_t k = 0; k < RD; k++) {
+                            v[k] = 0.0;
                             if (DV > 0 || k < dv) {
                                 ed[k] = edge_of(k0 + k);
                                 v[k] = msg[ed[k]];
                             }
+                        }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
                             if (DV > 0 || k < dv) {
@@ -2484,8 +2490,30 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                                 post += v[k];
                             }
 #pragma unroll
+                        for (uint32_t k = 0; k < RD; k++) v[k] = sum - v[k] + prior;
+                        if constexpr (DV != 0 && BPL_TANH_BATCH == 2) {
+                            double v2[2], y2[2];
+                            v2[0] = v[0]; v2[1] = v[1];
+                            bp_tanh_half_n<2, true>(v2, y2, 2);
+                            y[0] = y2[0]; y[1] = y2[1];
+                            v2[0] = v[2]; v2[1] = RD > 3 ? v[RD - 1] : 0.0;
+                            if (DV < 0 && __ballot(dv == RD) != 0) bp_tanh_half_n<2, true>(v2, y2, 2);
+                            else bp_tanh_half_n<2, true>(v2, y2, 1);
+                            y[2] = y2[0];
+                            if (RD > 3) y[RD - 1] = y2[1];
+                        } else if constexpr (DV != 0 && BPL_TANH_BATCH > 2) {
+                            // (the tanh of a bit's three or four messages as one batch: the polynomial's constants
+                            // are built once; the last of the batch only when some bit of the wave has that many checks)
+                            if (DV > 0 || __ballot(dv == RD) != 0) bp_tanh_half_n<(int)RD, true>(v, y, (int)RD);
+                            else bp_tanh_half_n<(int)RD, true>(v, y, (int)RD - 1);
+                        } else {
+#pragma unroll
+                            for (uint32_t k = 0; k < RD; k++)
+                                if (DV > 0 || k < dv) y[k] = bp_tanh_half<true>(v[k]);
+                        }
+#pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) msg[ed[k]] = bp_tanh_half<true>(sum - v[k] + prior);
+                            if (DV > 0 || k < dv) msg[ed[k]] = y[k];
                     } else {
                         for (uint32_t k = 0; k < dv; k++) {
                             const double vv = msg[edge_of(k0 + k)];
