@@ -940,7 +940,10 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
 #pragma unroll
             for (uint32_t r = 0; r < 4; r++)
                 if (r < rounds) {
-                    const uint32_t w = lane + 64 * r;
+                    // (w is the same for every shot of this wave: left to the compiler, the first Philox product of each of
+                    // the four words is computed once, spilled, and read back from scratch memory for every shot)
+                    uint32_t w = lane + 64 * r;
+                    asm volatile("" : "+v"(w));
                     if (w < Wn && !bsc_block(q, a.gap.inv_log2q, k0, k1, s_lo, s_hi, w, 0, bits_in_word(g.n, w), xs[r], ps[r])) pend |= 1u << r;
                 }
             uint32_t tb = 1;
