@@ -942,9 +942,12 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
                 if (r < rounds) {
                     // (w is the same for every shot of this wave: left to the compiler, the first Philox product of each of
                     // the four words is computed once, spilled, and read back from scratch memory for every shot)
-                    uint32_t w = lane + 64 * r;
-                    asm volatile("" : "+v"(w));
-                    if (w < Wn && !bsc_block(q, a.gap.inv_log2q, k0, k1, s_lo, s_hi, w, 0, bits_in_word(g.n, w), xs[r], ps[r])) pend |= 1u << r;
+                    // (likewise the ten round keys of Philox, the same for every shot: they are built, kept in scalar
+                    // registers beyond the budget and fetched lane by lane from a spill register, a vector instruction
+                    // each; with the key made opaque they are scalar additions in place)
+                    uint32_t w = lane + 64 * r, kk0 = k0, kk1 = k1;
+                    asm volatile("" : "+v"(w), "+s"(kk0), "+s"(kk1));
+                    if (w < Wn && !bsc_block(q, a.gap.inv_log2q, kk0, kk1, s_lo, s_hi, w, 0, bits_in_word(g.n, w), xs[r], ps[r])) pend |= 1u << r;
                 }
             uint32_t tb = 1;
             while (__ballot(pend != 0)) {
@@ -953,7 +956,9 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
                     uint64_t x = r == 0 ? xs[0] : (r == 1 ? xs[1] : (r == 2 ? xs[2] : xs[3]));
                     uint32_t pp = r == 0 ? ps[0] : (r == 1 ? ps[1] : (r == 2 ? ps[2] : ps[3]));
                     const uint32_t w = lane + 64 * r;
-                    const bool done = bsc_block(q, a.gap.inv_log2q, k0, k1, s_lo, s_hi, w, tb, bits_in_word(g.n, w), x, pp);
+                    uint32_t kk0 = k0, kk1 = k1;
+                    asm volatile("" : "+s"(kk0), "+s"(kk1));
+                    const bool done = bsc_block(q, a.gap.inv_log2q, kk0, kk1, s_lo, s_hi, w, tb, bits_in_word(g.n, w), x, pp);
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++)
                         if (r == u) {
