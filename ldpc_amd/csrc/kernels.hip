@@ -2236,6 +2236,19 @@ __host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t co
 #define BPL_STAMP(k) do { } while (0)
 #endif
 
+// The lane index, computed where it is asked for.  Everything a phase of bp_lds_kernel derives from its thread index
+// (addresses of its words, rows, shuffle partners) is the same for every shot, so the compiler computes it once at the
+// top of the kernel, cannot keep it in 72 registers across the check rows, and reads it back from scratch memory in
+// every phase of every shot: a few hundred cycles of latency each time, in series.  A phase that starts from this
+// (volatile: neither hoisted nor shared) recomputes those values with a handful of instructions instead.
+__device__ inline uint32_t bpl_lane()
+{
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+#define BPL_FRESH() const uint32_t lane = bpl_lane(), tid = wv * 64u + lane
+
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
 template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
 {
@@ -2329,10 +2342,12 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         const uint64_t myi_v = sh_queue[turn];
         const uint64_t myi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(myi_v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)myi_v);
         if (myi >= a.n_shots) break;
-        if (tid == 0) *sh_fail = 0;
         BPL_STAMP(0);
         bool asked = false;
         const uint64_t shot = a.first_shot + myi;
+        {
+        BPL_FRESH();
+        if (tid == 0) *sh_fail = 0;
         // ---- the shot's error word (or the caller's), decision words, messages = the prior (:60-68)
         for (uint32_t w = tid; w < Wn; w += NT) {
             const uint32_t nb = bits_in_word(n, w);
@@ -2360,8 +2375,11 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         }
         if (!FIRST_BY_TABLE)
             for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
+        }
         __syncthreads();
         BPL_STAMP(1);
+        {
+        BPL_FRESH();
         // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision: every set
         // bit of the error toggles its checks (few bits are set: E gathers become weight * degree atomics in LDS).  The
         // bit update keeps the residual current from then on.
@@ -2383,6 +2401,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 if (lane == 0) rw[c0 >> 6] ^= odd;
             }
         }
+        }
         uint32_t iter = 0, ran = 0;
         bool conv, compared = false, last_one = false;
         BPL_STAMP(2);
@@ -2391,6 +2410,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             // wave reads all of it: no flag to share)
             __syncthreads();
             {
+                BPL_FRESH();
+                (void)tid;
                 uint32_t r = 0;
                 for (uint32_t w = lane; w < 2 * Wm; w += 64) r |= rw32[w];
                 conv = __ballot(r != 0) == 0;
@@ -2410,8 +2431,11 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             const uint32_t t = iter + 1;
             const bool save = saved != nullptr && t >= 6 && !(t & 1u) && !last_one;
             compared = save && t >= 8;
-            if (compared && tid == 0) *sh_flag = 0;
             const bool by_table = FIRST_BY_TABLE && iter == 0;
+            {
+            BPL_FRESH();
+            (void)lane;
+            if (compared && tid == 0) *sh_flag = 0;
             // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
             for (uint32_t c = tid; c < m && !by_table; c += NT) {
                 const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
@@ -2452,8 +2476,11 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     }
                 }
             }
+            }
             __syncthreads();
             BPL_STAMP(4);
+            {
+            BPL_FRESH();
             // ---- update_bits (:168-180) + hard decision (:100-113), in place: check messages in, tanh((sum - own + prior) / 2)
             // out; 64 consecutive bits per wave and trip, so a ballot is the decision word
             unsigned long long next_i = 0;
@@ -2548,9 +2575,11 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                 if (tid == 0) sh_queue[turn ^ 1u] = next_i;
                 asked = true;
             }
+            }
             BPL_STAMP(by_table ? 5 : 6);
             if (save) {   // (wave-uniform; only runs that are still going after five iterations come here)
                 __syncthreads();
+                BPL_FRESH();
                 bool differs = false;
                 for (uint32_t e = tid; e < E; e += NT) {
                     const unsigned long long nb = (unsigned long long)__double_as_longlong(msg[e]);
@@ -2564,6 +2593,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             if (!by_table) ran++;   // (iterations of message arithmetic: what rooflines are priced on)
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
+        BPL_FRESH();
         if (tid == 0 && !asked) sh_queue[turn ^ 1u] = atomicAdd(a.queue, 1ull);   // (a shot that stopped before its first update)
         const bool det = !conv;
         bool fail = false;
