@@ -20,8 +20,8 @@ namespace ldpc {
 // BP_K(x) builds x where it is used instead: two scalar moves that cannot be hoisted (volatile), on the scalar unit's
 // own issue port.  bp_lds_kernel asks for it (CSS example 150 -> 128 ms); bp_kernel, with 128 registers, measured 6 %
 // slower with it and keeps the compiler's choice.  The values are the same either way.  (Tried on the CSS example and
-// C1, per 2^22 shots on one box, against 129 / 105.7 ms: one fixed register pair s[98:99] so that the pair always goes
-// into v_fma_f64 as it is, 141 / 104.8; a pair built by 64-bit scalar operations, 129.4 / 106.1 -- the scalar unit issues
+// C1, per 2^22 shots on one box, against 129 / 105.7 ms: fixed register pairs (one, or two or four taken in turn) so that a pair always
+// goes into v_fma_f64 as it is, 141 / 101.8; a pair built by 64-bit scalar operations, 129.4 / 106.1 -- the scalar unit issues
 // one instruction per SIMD turn like the vector unit and becomes the busier one; log1p of a check row's batch with the
 // constants built once per batch, 149 / 105.9, more registers spilled.)
 template <bool SK, unsigned long long BITS> __device__ inline double bp_k64()
