@@ -72,6 +72,35 @@ def test_lds_decode_batch_and_negative_prior(monkeypatch):
         assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"]), p
 
 
+def test_lds_negative_prior_on_odd_and_mixed_check_degrees(monkeypatch):
+    """The residual of the stop test starts as syndrome ^ H * (all ones) when the prior is negative: the parity of every
+    check's degree.  Checks of odd degree (3, 7: a constant word), of mixed degree (read from the graph) and of even
+    degree, from words and from given syndromes, against the other forms bit for bit."""
+    from tests.gpu_util import random_sparse_rows
+    rng = np.random.default_rng(4)
+    codes = [LinearCode.random_regular_code(210, 90, 3, 7, seed=5), LinearCode.random_regular_code(90, 90, 3, 3, seed=6),
+             LinearCode.random_regular_code(96, 72, 3, 4, seed=2),
+             LinearCode.from_parity_check_matrix(130, random_sparse_rows(rng, 130, 70, 7))]
+    for code in codes:
+        n, m, shots = code.len(), code.num_checks(), 260
+        oc = oracle_code(code)
+        words = np.stack([orc.sample_bsc_words(8, i, 0.06, n) for i in range(shots)]).reshape(shots, nwords(n))
+        syn = np.stack([oc.syndrome_words(words[i]) for i in range(shots)]).reshape(shots, max(nwords(m), 1))
+
+        def run():
+            dec = BpDecoder(code, 0.7, 9)
+            do, di = dev_u64(words.shape), dev_u32((shots,))
+            dec.decode_batch(shots, to_dev_u64(words), do, di)
+            dc_, dj = dev_u64(words.shape), dev_u32((shots,))
+            dec.correction_for_batch(shots, to_dev_u64(syn), dc_, dj)
+            cnt = dec.mc_run(0.7, 3, 0, 400)
+            return host_u64(do), host_u32(di), host_u64(dc_), host_u32(dj), cnt
+
+        out = _forms(monkeypatch, run)
+        assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"]), (n, m)
+        assert (out["lds"][1] == out["lds"][3]).all()    # the same runs from the word and from its syndrome
+
+
 def test_lds_mc_counters_flags_and_split(monkeypatch):
     code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
 
