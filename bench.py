@@ -108,6 +108,20 @@ def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None):
                                                          "(replayed, not a counter of this run)" % pmc}
 
 
+def flip_binder():
+    """What binds the headline kernel (for the LDS-resident flip kernel the HBM fraction is small by
+    construction): the pipe utilisation of the tracked counter pass, replayed, with its source named."""
+    path = "profiles/r02_flip_pipes.json"
+    text = "not HBM: the dependent chain of a flip pass (8 flips per ~1200 cycles per wave) x the 81 shots a CU's LDS holds"
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path)) as f:
+            d = json.load(f)
+        return {"what": text, "valu_pipe_busy": d["valu_pipe_busy"], "valu_instructions_per_shot": d["valu_instructions_per_shot"],
+                "source": path + " (replayed, not a counter of this run)"}
+    except (OSError, KeyError, ValueError):
+        return {"what": text, "valu_pipe_busy": None, "source": None}
+
+
 def recorded_traffic(shots_per_launch):
     """HBM-side bytes per launch, NOT measured in this run: the per-shot figure of the rocprofv3 PMC passes over this
     same command (fabric read + write requests of the flip kernel, kept in FLIP_PMC) times this run's shots per
@@ -330,6 +344,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "stub" if stub else ldpc_amd.last_kernel_name(), "kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
+                "binder": flip_binder(),
             },
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
         }
