@@ -2214,6 +2214,10 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #ifndef BPL_CHECK_BATCH
 #define BPL_CHECK_BATCH 0                // bp_kernel's batch sizes (batches of 2 spill less at 72 registers and measured slower: CSS 161 -> 216 ms)
 #endif
+#ifndef BPL_PERIOD_FROM
+#define BPL_PERIOD_FROM 6               // first (even) iteration whose bit messages are kept for the period test (CSS example:
+                                        // 2 and 4 end no run earlier and cost saves, 138 / 129 against 127.6 ms; 8 ends runs later, 129)
+#endif
 #ifndef BPL_WAVES_PER_SIMD
 #define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
 #endif
@@ -2429,8 +2433,8 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             }
             last_one = periodic;
             const uint32_t t = iter + 1;
-            const bool save = saved != nullptr && t >= 6 && !(t & 1u) && !last_one;
-            compared = save && t >= 8;
+            const bool save = saved != nullptr && t >= BPL_PERIOD_FROM && !(t & 1u) && !last_one;
+            compared = save && t >= BPL_PERIOD_FROM + 2;
             const bool by_table = FIRST_BY_TABLE && iter == 0;
             {
             BPL_FRESH();
