@@ -23,7 +23,9 @@ namespace ldpc {
 // C1, per 2^22 shots on one box, against 129 / 105.7 ms: fixed register pairs (one, or two or four taken in turn) so that a pair always
 // goes into v_fma_f64 as it is, 141 / 101.8; a pair built by 64-bit scalar operations, 129.4 / 106.1 -- the scalar unit issues
 // one instruction per SIMD turn like the vector unit and becomes the busier one; log1p of a check row's batch with the
-// constants built once per batch, 149 / 105.9, more registers spilled.)
+// constants built once per batch, 149 / 105.9, more registers spilled; the compiler's own 64-bit scalar constants made
+// opaque by an empty asm ("+s"), which go into v_fma_f64 without vector moves -- 13 vector instructions fewer per edge of a
+// check row -- 130 / 109: the loops wait on their dependent chains, not on instruction issue.)
 template <bool SK, unsigned long long BITS> __device__ inline double bp_k64()
 {
     if constexpr (SK) {
