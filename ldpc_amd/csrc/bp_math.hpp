@@ -19,7 +19,7 @@ namespace ldpc {
 // they are spilled and come back from scratch memory inside the check and bit updates.  With SK (scalar constants)
 // BP_K(x) builds x where it is used instead: two scalar moves that cannot be hoisted (volatile), on the scalar unit's
 // own issue port.  bp_lds_kernel asks for it (CSS example 150 -> 128 ms); bp_kernel, with 128 registers, measured 6 %
-// slower with it and keeps the compiler's choice.  The values are the same either way.  (Tried on the CSS example and
+// slower with it (5 % with it in the bit update alone, the streamed form likewise) and keeps the compiler's choice.  The values are the same either way.  (Tried on the CSS example and
 // C1, per 2^22 shots on one box, against 129 / 105.7 ms: fixed register pairs (one, or two or four taken in turn) so that a pair always
 // goes into v_fma_f64 as it is, 141 / 101.8; a pair built by 64-bit scalar operations, 129.4 / 106.1 -- the scalar unit issues
 // one instruction per SIMD turn like the vector unit and becomes the busier one; log1p of a check row's batch with the
