@@ -2218,8 +2218,13 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #define BPL_PERIOD_FROM 6               // first (even) iteration whose bit messages are kept for the period test (CSS example:
                                         // 2 and 4 end no run earlier and cost saves, 138 / 129 against 127.6 ms; 8 ends runs later, 129)
 #endif
+#ifndef BPL_SK
+#define BPL_SK true                     // polynomial constants built at their use by scalar moves (bp_math.hpp)
+#endif
 #ifndef BPL_WAVES_PER_SIMD
 #define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
+                                        // (end of round, CSS example / C1 ms per 2^22 shots: 4 waves 225 / 102 and 5 waves 167 / 103 with the
+                                        // compiler's constants, 5 waves 164 / 101, 7 waves 131 / 102, 8 waves, six workgroups, 148 / 103)
 #endif
 
 // LDS of a workgroup, in u64 words: messages, error / decision / syndrome / residual words, gap table, queue slot,
@@ -2291,7 +2296,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         for (uint32_t r = tid; r <= a.l_rows; r += NT) lptr[r] = (uint16_t)a.l_ptr[r];
         for (uint32_t k = tid; k < a.l_nnz; k += NT) lidx[k] = (uint16_t)a.l_idx[k];
     }
-    const double prior = a.prior, t_prior_v = bp_tanh_half<true>(prior);
+    const double prior = a.prior, t_prior_v = bp_tanh_half<BPL_SK>(prior);
     // (wave-uniform values are moved to scalar registers by hand where the compiler would hold them per lane)
     const double t_prior = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t_prior_v)),
                                             __builtin_amdgcn_readfirstlane(__double2loint(t_prior_v)));
@@ -2306,7 +2311,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
         double x[DC], out[DC];
 #pragma unroll
         for (int j = 0; j < DC; j++) x[j] = t_prior;
-        bp_check_row<DC, BPL_CHECK_BATCH, true>(x, 0u, out);
+        bp_check_row<DC, BPL_CHECK_BATCH, BPL_SK>(x, 0u, out);
         const double v0 = out[0];
         if (tid < 5 * 16) {
             const uint32_t d = tid >> 4, pat = tid & 15;
@@ -2322,7 +2327,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
             tab_p[d * 16 + pat] = post;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++)
-                if (k < d) tab_t[((d - 1) * 16 + pat) * 4 + k] = bp_tanh_half<true>(sum - v[k] + prior);
+                if (k < d) tab_t[((d - 1) * 16 + pat) * 4 + k] = bp_tanh_half<BPL_SK>(sum - v[k] + prior);
         }
     }
     if (tid == 0)
@@ -2447,7 +2452,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                     double x[DC], out[DC];
 #pragma unroll
                     for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
-                    bp_check_row<DC, BPL_CHECK_BATCH, true>(x, sbit ? 0x80000000u : 0u, out);
+                    bp_check_row<DC, BPL_CHECK_BATCH, BPL_SK>(x, sbit ? 0x80000000u : 0u, out);
 #pragma unroll
                     for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
                 } else {
@@ -2465,7 +2470,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
 #pragma unroll
                         for (uint32_t j = 0; j < REG_DEG; j++)
                             if (j < dc) {
-                                double v = 2.0 * bp_ref_atanh<true>(bp_div_prod(prod, t[j]));
+                                double v = 2.0 * bp_ref_atanh<BPL_SK>(bp_div_prod(prod, t[j]));
                                 if (sbit) v *= -1.0;
                                 msg[e0 + j] = v;
                             }
@@ -2473,7 +2478,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         double prod = 1.0;
                         for (uint32_t j = 0; j < dc; j++) prod *= msg[e0 + j];
                         for (uint32_t j = 0; j < dc; j++) {
-                            double v = 2.0 * bp_ref_atanh<true>(bp_div_prod(prod, msg[e0 + j]));
+                            double v = 2.0 * bp_ref_atanh<BPL_SK>(bp_div_prod(prod, msg[e0 + j]));
                             if (sbit) v *= -1.0;
                             msg[e0 + j] = v;
                         }
@@ -2533,22 +2538,22 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         if constexpr (DV != 0 && BPL_TANH_BATCH == 2) {
                             double v2[2], y2[2];
                             v2[0] = v[0]; v2[1] = v[1];
-                            bp_tanh_half_n<2, true>(v2, y2, 2);
+                            bp_tanh_half_n<2, BPL_SK>(v2, y2, 2);
                             y[0] = y2[0]; y[1] = y2[1];
                             v2[0] = v[2]; v2[1] = RD > 3 ? v[RD - 1] : 0.0;
-                            if (DV < 0 && __ballot(dv == RD) != 0) bp_tanh_half_n<2, true>(v2, y2, 2);
-                            else bp_tanh_half_n<2, true>(v2, y2, 1);
+                            if (DV < 0 && __ballot(dv == RD) != 0) bp_tanh_half_n<2, BPL_SK>(v2, y2, 2);
+                            else bp_tanh_half_n<2, BPL_SK>(v2, y2, 1);
                             y[2] = y2[0];
                             if (RD > 3) y[RD - 1] = y2[1];
                         } else if constexpr (DV != 0 && BPL_TANH_BATCH > 2) {
                             // (the tanh of a bit's three or four messages as one batch: the polynomial's constants
                             // are built once; the last of the batch only when some bit of the wave has that many checks)
-                            if (DV > 0 || __ballot(dv == RD) != 0) bp_tanh_half_n<(int)RD, true>(v, y, (int)RD);
-                            else bp_tanh_half_n<(int)RD, true>(v, y, (int)RD - 1);
+                            if (DV > 0 || __ballot(dv == RD) != 0) bp_tanh_half_n<(int)RD, BPL_SK>(v, y, (int)RD);
+                            else bp_tanh_half_n<(int)RD, BPL_SK>(v, y, (int)RD - 1);
                         } else {
 #pragma unroll
                             for (uint32_t k = 0; k < RD; k++)
-                                if (DV > 0 || k < dv) y[k] = bp_tanh_half<true>(v[k]);
+                                if (DV > 0 || k < dv) y[k] = bp_tanh_half<BPL_SK>(v[k]);
                         }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
@@ -2561,7 +2566,7 @@ template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PE
                         }
                         for (uint32_t k = 0; k < dv; k++) {
                             const uint32_t e = edge_of(k0 + k);
-                            msg[e] = bp_tanh_half<true>(sum - msg[e] + prior);
+                            msg[e] = bp_tanh_half<BPL_SK>(sum - msg[e] + prior);
                         }
                     }
                     dec = post < 0.0;
