@@ -2208,7 +2208,14 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 // and sums), so the results are bit-identical to it; nothing of an iteration touches HBM, and a shot that does not
 // converge holds one workgroup, not a 64-slot group.  Posterior / message outputs are left to the other forms.
 // ---------------------------------------------------------------------------
-constexpr uint32_t BPL_THREADS = 320;   // 5 waves: 300 / 900 checks and 625 / 1200 bits (C3, C1) leave few lanes idle
+// Four waves per shot.  (Five, 320 threads, leave fewer lanes idle on 300 / 900 checks and 625 / 1200 bits, C3 / C1, and
+// were the form of most of round 2; with four, six or seven shots fit a CU instead of five, and the phases of a shot
+// that run on few lanes -- sampling, stop tests, the failure test -- hide behind more neighbours: CSS example 131 ->
+// 125 ms, C1 102.5 -> 101.8 ms per 2^22 shots on one box.  Three waves: 125 / 118; two: 131 / 144.)
+#ifndef BPL_NT
+#define BPL_NT 256
+#endif
+constexpr uint32_t BPL_THREADS = BPL_NT;
 // first-iteration table (see the kernel): bit messages [degree 1..4][sign pattern][edge] and posteriors [degree 0..4][pattern]
 constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #ifndef BPL_CHECK_BATCH
@@ -2222,8 +2229,8 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #define BPL_SK true                     // polynomial constants built at their use by scalar moves (bp_math.hpp)
 #endif
 #ifndef BPL_WAVES_PER_SIMD
-#define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that five workgroups fit a CU when their LDS does
-                                        // (end of round, CSS example / C1 ms per 2^22 shots: 4 waves 225 / 102 and 5 waves 167 / 103 with the
+#define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that seven four-wave workgroups fit a CU when their LDS does
+                                        // (with five-wave workgroups, CSS example / C1 ms per 2^22 shots: 4 waves 225 / 102 and 5 waves 167 / 103 with the
                                         // compiler's constants, 5 waves 164 / 101, 7 waves 131 / 102, 8 waves, six workgroups, 148 / 103)
 #endif
 
