@@ -563,16 +563,14 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     bool stream = by_memory < 128 || (g.E >= 3000 && work_groups <= 256) || (g.E >= 200 && work_groups <= 128);
     if (switches().bp_path == 1) stream = true;   // A/B and test aid
     else if (switches().bp_path == 2) stream = false;
-    // Small codes with regular checks: the messages of a shot live in LDS, one workgroup per shot in flight
-    // (bp_lds_kernel).  Measured against the forms above (scripts/bp_lds_small.py; C1 / (3,4) E = 2100 / (3,6) E = 6000):
-    // one shot 0.3 -> 0.07 ms, 16,384 shots 2.7-3x, 2^21 shots 1.24x / 1.40x / 1.09x; the CSS example's halves (check
-    // degree 7, bits of degree 3 and 4) run level with bp_kernel at 2^22 shots and ahead below.  Posterior / message
-    // outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and forbid it.
-    // (a code that leaves room for one workgroup per CU only, E >= 10^4, falls behind on calls of 10^6 shots: 0.83-0.9x)
-    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out &&
-                          (switches().bp_path == 3 ||
-                           (switches().bp_path == 0 && (r.n_shots <= (1ull << 18) ||
-                                                        bp_lds_workgroups(g, dec->reg_dc, dec->reg_dv) >= 2 * device_cu_count())));
+    // Codes whose messages of a shot fit LDS (E * 8 B + words <= 150 KB): one workgroup per shot in flight
+    // (bp_lds_kernel), of 256 threads where five or more shots fit a CU and up to 1024 where fewer do (bp_lds_shape).
+    // Measured against the forms above: one shot 0.3 -> 0.07 ms; 2^22 shots C1 2.0x, CSS example 4x; codes of which a CU
+    // holds one shot, 2^20 shots: (3,6) E = 15,000 1.6x, E = 18,000 1.4-1.6x, (3,7) E = 12,600 1.8x (scripts/bp_lds_big.py;
+    // with 256-thread workgroups these lost, 0.83-0.9x, and the rule used to send them to bp_kernel).  Posterior /
+    // message outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and
+    // forbid it.
+    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out && (switches().bp_path == 3 || switches().bp_path == 0);
     if (lds_form) {
         stream = false;
         groups = 0;

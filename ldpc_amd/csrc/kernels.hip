@@ -2215,7 +2215,7 @@ template <int DC, int DV> __global__ __launch_bounds__(512, 4) void bp_kernel(De
 #ifndef BPL_NT
 #define BPL_NT 256
 #endif
-constexpr uint32_t BPL_THREADS = BPL_NT;
+constexpr uint32_t BPL_THREADS = BPL_NT, BPL_MAX_THREADS = 1024;
 // first-iteration table (see the kernel): bit messages [degree 1..4][sign pattern][edge] and posteriors [degree 0..4][pattern]
 constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #ifndef BPL_CHECK_BATCH
@@ -2266,11 +2266,11 @@ __device__ inline uint32_t bpl_lane()
 #define BPL_FRESH() const uint32_t lane = bpl_lane(), tid = wv * 64u + lane
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
-template <int DC, int DV> __global__ __launch_bounds__(BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
+template <int DC, int DV> __global__ __launch_bounds__(BPL_MAX_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr uint32_t NT = BPL_THREADS;
+    const uint32_t NT = blockDim.x;   // (a multiple of 64 chosen by bp_lds_shape)
     const uint32_t n = g.n, m = g.m, E = g.E, Wn = (n + 63) / 64, Wm = (m + 63) / 64;
     double *msg = (double *)lds;
     uint64_t *ew = lds + E, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
@@ -3303,6 +3303,7 @@ Switches read_switches()
         s.bp_handoff = (uint32_t)std::strtoul(e, nullptr, 10);
     }
     s.bp_profile = std::getenv("LDPC_HIP_BP_PROFILE") != nullptr;
+    if (const char *e = std::getenv("LDPC_HIP_BP_LDS_THREADS")) s.bp_lds_threads = (uint32_t)std::max(64, std::min(1024, std::atoi(e))) / 64 * 64;
     s.bp_stream_skew = std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
     if (const char *e = std::getenv("LDPC_HIP_BP_TAIL_BURST")) s.bp_tail_burst = std::max(1, std::atoi(e));
     s.bp_no_compact = std::getenv("LDPC_HIP_BP_NO_COMPACT") != nullptr;
@@ -3524,22 +3525,22 @@ bool bp_lds_serves(const DeviceGraph &g, int dc)
 // The launch shape of the LDS form for a code: as many graph copies in LDS as cost no resident workgroup (asked of the
 // runtime once per device, kernel form and footprint)
 struct BpLdsShape {
-    uint32_t copies, workgroups;
+    uint32_t copies, workgroups, threads;
     size_t lds;
 };
 static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_rows = 0, uint32_t l_nnz = 0)
 {
     static std::mutex mu;
-    static std::map<std::tuple<int, const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, BpLdsShape> cache;
+    static std::map<std::tuple<int, const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, BpLdsShape> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const void *fn = (const void *)bp_lds_kernel_for(dc, dv);
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_tuple(dev, fn, g.E, g.n, g.m, l_rows, l_nnz);
+    const auto key = std::make_tuple(dev, fn, g.E, g.n, g.m, l_rows, l_nnz, switches().bp_lds_threads);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const bool mixed = !(dv == 3);
-    BpLdsShape best{0, 0, 0};
+    BpLdsShape best{0, 0, BPL_THREADS, 0};
     // (the most workgroups, then the most copies; the logical rows only when there are some and u16 holds their offsets)
     const uint32_t most = l_rows && l_nnz < 65536 ? 3 : 2;
     for (uint32_t copies = 0; copies <= most; copies++) {
@@ -3549,7 +3550,35 @@ static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) break;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)BPL_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = copies == 0 ? 1 : 0;
         const uint32_t wgs = (uint32_t)per_cu * device_cu_count();
-        if (wgs && wgs >= best.workgroups) best = BpLdsShape{copies, wgs, lds};
+        if (wgs && wgs >= best.workgroups) best = BpLdsShape{copies, wgs, BPL_THREADS, lds};
+    }
+    // Codes of which few shots fit a CU's LDS get more waves per shot: the workgroup size of 256, 512, 768 or 1024 threads
+    // that puts the most threads on a CU with at most six waves per SIMD (seven measured slower, and the runtime's
+    // occupancy answer for odd sizes was not what the hardware did), no wider than the code has checks or half its bits.
+    // Measured on (3,6)-regular codes, 2^18 shots: E = 6000 512 threads 14.9 ms against 17.0 with 256, E = 9000 768
+    // threads 24.8 against 33.7, E = 15,000 1024 threads 54 against 98 (scripts/bp_lds_threads.py).
+    if (best.workgroups) {
+        const uint32_t per_cu = best.workgroups / device_cu_count();
+        const uint32_t useful = (std::max(g.m, (g.n + 1) / 2) + 63) / 64 * 64;
+        uint32_t threads = BPL_THREADS;
+        if (switches().bp_lds_threads) threads = switches().bp_lds_threads;
+        else if (per_cu < 5) {
+            uint32_t most_threads = per_cu * BPL_THREADS;
+            for (uint32_t t = 512; t <= BPL_MAX_THREADS && t <= std::max(useful, BPL_THREADS); t += 256) {
+                const uint32_t fit = std::min(per_cu, 24u / (t / 64));
+                if (fit * t > most_threads) {
+                    most_threads = fit * t;
+                    threads = t;
+                }
+            }
+        }
+        if (threads != BPL_THREADS) {
+            int fit = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fn, (int)threads, best.lds) == hipSuccess && fit >= 1) {
+                best.threads = threads;
+                best.workgroups = std::min((uint32_t)fit, std::max(1u, switches().bp_lds_threads ? 28u / (threads / 64) : 24u / (threads / 64))) * device_cu_count();
+            }
+        }
     }
     cache[key] = best;
     return best;
@@ -3569,9 +3598,9 @@ hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, 
     if (e != hipSuccess) return e;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
     if (switches().debug)
-        std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups\n", sh.lds, sh.copies, grid);
+        std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups of %u threads\n", sh.lds, sh.copies, grid, sh.threads);
     g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : dc == 3 ? "bp_lds_kernel<3>" : "bp_lds_kernel<0>";
-    hipLaunchKernelGGL(k, dim3(grid), dim3(BPL_THREADS), sh.lds, st, g, a, sh.copies);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(sh.threads), sh.lds, st, g, a, sh.copies);
     return hipGetLastError();
 }
 

@@ -101,6 +101,42 @@ def test_lds_negative_prior_on_odd_and_mixed_check_degrees(monkeypatch):
         assert (out["lds"][1] == out["lds"][3]).all()    # the same runs from the word and from its syndrome
 
 
+def test_lds_workgroup_sizes_change_nothing(monkeypatch):
+    """bp_lds_shape gives codes of which few shots fit a CU's LDS wider workgroups (512, 768, 1024 threads); a thread
+    works the checks / bits tid, tid + threads, ...: the results do not depend on the width.  The chosen widths on three
+    such codes against the persistent kernel, and forced widths (LDPC_HIP_BP_LDS_THREADS) on a small code, bit for bit."""
+    for (n, m, p, shots) in [(2000, 1000, 0.03, 500), (3000, 1500, 0.03, 400), (5000, 2500, 0.04, 300)]:
+        code = LinearCode.random_regular_code(n, m, 3, 6, seed=4)
+        oc = oracle_code(code)
+        syn = np.stack([oc.syndrome_words(orc.sample_bsc_words(12, i, p, n)) for i in range(shots)])
+
+        def run():
+            dec = BpDecoder(code, p, 40)
+            dc_, di = dev_u64((shots, nwords(n))), dev_u32((shots,))
+            dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di)
+            return host_u64(dc_), host_u32(di), dec.mc_run(p, 5, 3, 2000)
+
+        out = _forms(monkeypatch, run, forms=("lds", "persistent"))
+        assert _same(out["lds"], out["persistent"]), n
+        monkeypatch.delenv("LDPC_HIP_BP_PATH", raising=False)
+        ldpc_amd.reload_switches()
+        dflt = run()   # (and the LDS form is what a plain call takes, however large the code, as long as a shot fits)
+        assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel") and _same(dflt, out["lds"])
+    code = LinearCode.random_regular_code(700, 300, 3, 7, seed=3)
+    monkeypatch.setenv("LDPC_HIP_BP_PATH", "lds")
+    res = []
+    for threads in ("64", "192", "256", "448", "1024"):
+        monkeypatch.setenv("LDPC_HIP_BP_LDS_THREADS", threads)
+        ldpc_amd.reload_switches()
+        flags = dev_u8((3000,))
+        cnt = BpDecoder(code, 0.03, 25).mc_run(0.03, 8, 0, 3000, flags)
+        res.append((cnt, flags.cpu().numpy()))
+    monkeypatch.delenv("LDPC_HIP_BP_LDS_THREADS")
+    monkeypatch.delenv("LDPC_HIP_BP_PATH")
+    ldpc_amd.reload_switches()
+    assert all(_same(res[0], r) for r in res[1:])
+
+
 def test_lds_mc_counters_flags_and_split(monkeypatch):
     code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
 
