@@ -2266,11 +2266,13 @@ __device__ inline uint32_t bpl_lane()
 #define BPL_FRESH() const uint32_t lane = bpl_lane(), tid = wv * 64u + lane
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
-template <int DC, int DV> __global__ __launch_bounds__(BPL_MAX_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
+template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t NT = blockDim.x;   // (a multiple of 64 chosen by bp_lds_shape)
+    // (WIDE: a multiple of 64 chosen by bp_lds_shape for codes of which few shots fit a CU; the usual 256 as a constant
+    // is worth 2 % on C1)
+    const uint32_t NT = WIDE ? blockDim.x : BPL_THREADS;
     const uint32_t n = g.n, m = g.m, E = g.E, Wn = (n + 63) / 64, Wm = (m + 63) / 64;
     double *msg = (double *)lds;
     uint64_t *ew = lds + E, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
@@ -3502,16 +3504,20 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 }
 
 typedef void (*bp_lds_fn)(DeviceGraph, BpArgs, uint32_t);
-static bp_lds_fn bp_lds_kernel_for(int dc, int dv)
+template <bool WIDE> static bp_lds_fn bp_lds_kernel_of(int dc, int v)
+{
+    switch (dc) {
+    case 3: return v == 3 ? bp_lds_kernel<3, 3, WIDE> : v == -4 ? bp_lds_kernel<3, -4, WIDE> : bp_lds_kernel<3, 0, WIDE>;
+    case 4: return v == 3 ? bp_lds_kernel<4, 3, WIDE> : v == -4 ? bp_lds_kernel<4, -4, WIDE> : bp_lds_kernel<4, 0, WIDE>;
+    case 6: return v == 3 ? bp_lds_kernel<6, 3, WIDE> : v == -4 ? bp_lds_kernel<6, -4, WIDE> : bp_lds_kernel<6, 0, WIDE>;
+    case 7: return v == 3 ? bp_lds_kernel<7, 3, WIDE> : v == -4 ? bp_lds_kernel<7, -4, WIDE> : bp_lds_kernel<7, 0, WIDE>;
+    default: return v == -4 || v == 3 ? bp_lds_kernel<0, -4, WIDE> : bp_lds_kernel<0, 0, WIDE>;   // checks of any degree
+    }
+}
+static bp_lds_fn bp_lds_kernel_for(int dc, int dv, bool wide = false)
 {
     const int v = dv == 3 ? 3 : (dv == -4 || (dv >= 1 && dv <= 4)) ? -4 : 0;
-    switch (dc) {
-    case 3: return v == 3 ? bp_lds_kernel<3, 3> : v == -4 ? bp_lds_kernel<3, -4> : bp_lds_kernel<3, 0>;
-    case 4: return v == 3 ? bp_lds_kernel<4, 3> : v == -4 ? bp_lds_kernel<4, -4> : bp_lds_kernel<4, 0>;
-    case 6: return v == 3 ? bp_lds_kernel<6, 3> : v == -4 ? bp_lds_kernel<6, -4> : bp_lds_kernel<6, 0>;
-    case 7: return v == 3 ? bp_lds_kernel<7, 3> : v == -4 ? bp_lds_kernel<7, -4> : bp_lds_kernel<7, 0>;
-    default: return v == -4 || v == 3 ? bp_lds_kernel<0, -4> : bp_lds_kernel<0, 0>;   // checks of any degree
-    }
+    return wide ? bp_lds_kernel_of<true>(dc, v) : bp_lds_kernel_of<false>(dc, v);
 }
 
 // smallest LDS footprint of a workgroup (no graph copies)
@@ -3574,7 +3580,9 @@ static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_
         }
         if (threads != BPL_THREADS) {
             int fit = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fn, (int)threads, best.lds) == hipSuccess && fit >= 1) {
+            const void *wide = (const void *)bp_lds_kernel_for(dc, dv, true);
+            if (hipFuncSetAttribute(wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)best.lds) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, wide, (int)threads, best.lds) == hipSuccess && fit >= 1) {
                 best.threads = threads;
                 best.workgroups = std::min((uint32_t)fit, std::max(1u, switches().bp_lds_threads ? 28u / (threads / 64) : 24u / (threads / 64))) * device_cu_count();
             }
@@ -3589,11 +3597,11 @@ uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv) { return bp_lds
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
-    const bp_lds_fn k = bp_lds_kernel_for(dc, dv);
-    if (!k || a.post_out || a.chk_out) return hipErrorInvalidValue;
+    if (!bp_lds_kernel_for(dc, dv) || a.post_out || a.chk_out) return hipErrorInvalidValue;
     const bool logical = a.test == TEST_LOGICAL && a.l_rows;
     const BpLdsShape sh = bp_lds_shape(g, dc, dv, logical ? a.l_rows : 0, logical ? a.l_nnz : 0);
     if (!sh.workgroups) return hipErrorInvalidValue;
+    const bp_lds_fn k = bp_lds_kernel_for(dc, dv, sh.threads != BPL_THREADS);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
     if (e != hipSuccess) return e;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
