@@ -2269,7 +2269,7 @@ __device__ inline uint32_t bpl_lane()
 template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
 {
     extern __shared__ uint64_t lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the phases of a shot take their own, BPL_FRESH)
     // (WIDE: a multiple of 64 chosen by bp_lds_shape for codes of which few shots fit a CU; the usual 256 as a constant
     // is worth 2 % on C1)
     const uint32_t NT = WIDE ? blockDim.x : BPL_THREADS;
