@@ -570,7 +570,8 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // with 256-thread workgroups these lost, 0.83-0.9x, and the rule used to send them to bp_kernel).  Posterior /
     // message outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and
     // forbid it.
-    const bool lds_form = bp_lds_serves(g, dec->reg_dc) && !r.post_out && !r.chk_out && (switches().bp_path == 3 || switches().bp_path == 0);
+    const bool lds_form = !r.post_out && !r.chk_out && ((bp_lds_serves(g, dec->reg_dc) && (switches().bp_path == 3 || switches().bp_path == 0)) ||
+                                                        (bp_lds_hybrid_serves(g, dec->reg_dc, dec->reg_dv) && (switches().bp_path == 3 || switches().bp_path == 0)));
     if (lds_form) {
         stream = false;
         groups = 0;
@@ -581,7 +582,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp: %s E=%u waves=%u groups=%llu resident=%u per_group=%zu MiB\n", lds_form ? "lds" : stream ? "stream" : "persistent", g.E, waves,
                      (unsigned long long)groups, bp_resident_groups(waves, dec->reg_dc, dec->reg_dv), per_group >> 20);
-    if (lds_form) HIP_TRY(dec->workspace.reserve((size_t)bp_lds_workgroups(g, dec->reg_dc, dec->reg_dv) * g.E * 8));   // (saved states, bp_lds_kernel)
+    if (lds_form) HIP_TRY(dec->workspace.reserve(bp_lds_workspace_bytes(g, dec->reg_dc, dec->reg_dv)));   // (saved states, bp_lds_kernel)
     else HIP_TRY(dec->workspace.reserve(per_group * groups));
 
     BpArgs a{};

@@ -2237,12 +2237,13 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 // LDS of a workgroup, in u64 words: messages, error / decision / syndrome / residual words, gap table, queue slot,
 // then copies of the graph as u16 when they do not cost a resident workgroup (copies >= 1: bit -> edges, and bit ->
 // first edge for codes with bits of mixed degree; 2: bit -> checks as well; 3: the logical generators' rows of the CSS test)
-__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t copies, bool mixed_bits, uint32_t l_rows, uint32_t l_nnz)
+__host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t copies, bool mixed_bits, uint32_t l_rows, uint32_t l_nnz,
+                                               uint32_t e_lds = 0xFFFFFFFFu)   // (edges whose messages live in LDS: all, but for the hybrid form)
 {
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
     const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0) +
                         (copies >= 3 ? (size_t)l_rows + 1 + l_nnz : 0);
-    return (size_t)g.E + 2 * Wn + 2 * Wm + 34 + 2 + 5 + BPL_TABLE_WORDS + (u16s + 3) / 4;
+    return (size_t)std::min(g.E, e_lds) + 2 * Wn + 2 * Wm + 34 + 2 + 5 + BPL_TABLE_WORDS + (u16s + 3) / 4;
 }
 
 // (diagnostic build, -DBPL_PROF: wave 0 of workgroup 0 prints the cycles it spent in each phase)
@@ -2266,7 +2267,8 @@ __device__ inline uint32_t bpl_lane()
 #define BPL_FRESH() const uint32_t lane = bpl_lane(), tid = wv * 64u + lane
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
-template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies)
+template <int DC, int DV, bool WIDE, bool HYB = false>
+__global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies, uint32_t e_lds)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the phases of a shot take their own, BPL_FRESH)
@@ -2274,8 +2276,11 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
     // is worth 2 % on C1)
     const uint32_t NT = WIDE ? blockDim.x : BPL_THREADS;
     const uint32_t n = g.n, m = g.m, E = g.E, Wn = (n + 63) / 64, Wm = (m + 63) / 64;
+    // (HYB: a shot's messages do not fit LDS; those of the edges from e_lds on live in this workgroup's piece of a.msg,
+    // L2-resident: one workgroup per CU, a few MB per XCD)
+    const uint32_t EL = HYB ? e_lds : E;
     double *msg = (double *)lds;
-    uint64_t *ew = lds + E, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
+    uint64_t *ew = lds + EL, *dw = ew + Wn, *sw = dw + Wn, *rw = sw + Wm;
     uint32_t *q = (uint32_t *)(rw + Wm);
     uint32_t *sh_flag = q + 65, *sh_fail = q + 66;   // (the words after the gap table's 65)
     unsigned long long *sh_queue = (unsigned long long *)(rw + Wm + 34);   // (two slots, taken in turn: one barrier per hand-over)
@@ -2348,7 +2353,13 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
     // ones or the next ones, by parity.  From the sixth iteration on the even iterations leave their bit messages in
     // `saved` (global, this workgroup's) and compare with what is there; a periodic run takes at most one more
     // iteration and reports max_iter.  Results and counters are those of the full run (tests/test_gpu_bp_lds.py).
-    unsigned long long *saved = a.msg ? (unsigned long long *)a.msg + (size_t)blockIdx.x * E : nullptr;
+    unsigned long long *saved = a.msg ? (unsigned long long *)a.msg + (size_t)blockIdx.x * (2 * (size_t)E - EL) : nullptr;
+    double *gmsg = HYB ? (double *)(saved + E) : nullptr;
+    auto ldm = [&](uint32_t e) -> double { return !HYB || e < EL ? msg[e] : gmsg[e - EL]; };
+    auto stm = [&](uint32_t e, double v) {
+        if (!HYB || e < EL) msg[e] = v;
+        else gmsg[e - EL] = v;
+    };
     // (the index of the next shot is asked for at the start of the current one's first bit update and put in the
     // other queue slot at its end: the queue's round trip is off the path and the answer is not kept across a check row)
     if (tid == 0) sh_queue[0] = atomicAdd(a.queue, 1ull);
@@ -2392,7 +2403,7 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
             rw[w] = x ^ (init && DC > 0 && (DC & 1) ? valid : 0ull);
         }
         if (!FIRST_BY_TABLE)
-            for (uint32_t e = tid; e < E; e += NT) msg[e] = t_prior;
+            for (uint32_t e = tid; e < E; e += NT) stm(e, t_prior);
         }
         __syncthreads();
         BPL_STAMP(1);
@@ -2460,10 +2471,10 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                 if constexpr (DC > 0) {
                     double x[DC], out[DC];
 #pragma unroll
-                    for (int j = 0; j < DC; j++) x[j] = msg[c * (uint32_t)DC + j];
+                    for (int j = 0; j < DC; j++) x[j] = ldm(c * (uint32_t)DC + j);
                     bp_check_row<DC, BPL_CHECK_BATCH, BPL_SK>(x, sbit ? 0x80000000u : 0u, out);
 #pragma unroll
-                    for (int j = 0; j < DC; j++) msg[c * (uint32_t)DC + j] = out[j];
+                    for (int j = 0; j < DC; j++) stm(c * (uint32_t)DC + j, out[j]);
                 } else {
                     // checks of any degree: bp_kernel's general row, operation for operation
                     const uint32_t e0 = g.h_ptr[c], dc = g.h_ptr[c + 1] - e0;
@@ -2473,7 +2484,7 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
 #pragma unroll
                         for (uint32_t j = 0; j < REG_DEG; j++)
                             if (j < dc) {
-                                t[j] = msg[e0 + j];
+                                t[j] = ldm(e0 + j);
                                 prod *= t[j];
                             }
 #pragma unroll
@@ -2481,15 +2492,15 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                             if (j < dc) {
                                 double v = 2.0 * bp_ref_atanh<BPL_SK>(bp_div_prod(prod, t[j]));
                                 if (sbit) v *= -1.0;
-                                msg[e0 + j] = v;
+                                stm(e0 + j, v);
                             }
                     } else {
                         double prod = 1.0;
-                        for (uint32_t j = 0; j < dc; j++) prod *= msg[e0 + j];
+                        for (uint32_t j = 0; j < dc; j++) prod *= ldm(e0 + j);
                         for (uint32_t j = 0; j < dc; j++) {
-                            double v = 2.0 * bp_ref_atanh<BPL_SK>(bp_div_prod(prod, msg[e0 + j]));
+                            double v = 2.0 * bp_ref_atanh<BPL_SK>(bp_div_prod(prod, ldm(e0 + j)));
                             if (sbit) v *= -1.0;
-                            msg[e0 + j] = v;
+                            stm(e0 + j, v);
                         }
                     }
                 }
@@ -2523,7 +2534,7 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                             }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) msg[pk[k] & 0xFFFFu] = tab_t[((dv - 1) * 16 + pat) * 4 + k];
+                            if (DV > 0 || k < dv) stm(pk[k] & 0xFFFFu, tab_t[((dv - 1) * 16 + pat) * 4 + k]);
                         post = tab_p[dv * 16 + pat];
                     } else if (DV != 0 || dv <= RD) {
                         uint32_t ed[RD];
@@ -2533,7 +2544,7 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                             v[k] = 0.0;
                             if (DV > 0 || k < dv) {
                                 ed[k] = edge_of(k0 + k);
-                                v[k] = msg[ed[k]];
+                                v[k] = ldm(ed[k]);
                             }
                         }
 #pragma unroll
@@ -2566,16 +2577,16 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                         }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) msg[ed[k]] = y[k];
+                            if (DV > 0 || k < dv) stm(ed[k], y[k]);
                     } else {
                         for (uint32_t k = 0; k < dv; k++) {
-                            const double vv = msg[edge_of(k0 + k)];
+                            const double vv = ldm(edge_of(k0 + k));
                             sum += vv;
                             post += vv;
                         }
                         for (uint32_t k = 0; k < dv; k++) {
                             const uint32_t e = edge_of(k0 + k);
-                            msg[e] = bp_tanh_half<BPL_SK>(sum - msg[e] + prior);
+                            stm(e, bp_tanh_half<BPL_SK>(sum - ldm(e) + prior));
                         }
                     }
                     dec = post < 0.0;
@@ -2600,7 +2611,7 @@ template <int DC, int DV, bool WIDE> __global__ __launch_bounds__(WIDE ? BPL_MAX
                 BPL_FRESH();
                 bool differs = false;
                 for (uint32_t e = tid; e < E; e += NT) {
-                    const unsigned long long nb = (unsigned long long)__double_as_longlong(msg[e]);
+                    const unsigned long long nb = (unsigned long long)__double_as_longlong(ldm(e));
                     if (compared && saved[e] != nb) differs = true;
                     saved[e] = nb;
                 }
@@ -3503,7 +3514,7 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
     return hipGetLastError();
 }
 
-typedef void (*bp_lds_fn)(DeviceGraph, BpArgs, uint32_t);
+typedef void (*bp_lds_fn)(DeviceGraph, BpArgs, uint32_t, uint32_t);
 template <bool WIDE> static bp_lds_fn bp_lds_kernel_of(int dc, int v)
 {
     switch (dc) {
@@ -3518,6 +3529,19 @@ static bp_lds_fn bp_lds_kernel_for(int dc, int dv, bool wide = false)
 {
     const int v = dv == 3 ? 3 : (dv == -4 || (dv >= 1 && dv <= 4)) ? -4 : 0;
     return wide ? bp_lds_kernel_of<true>(dc, v) : bp_lds_kernel_of<false>(dc, v);
+}
+
+// The hybrid form (one instantiation: check degree 6, bit degree 3, i.e. C2): a shot's messages beyond what LDS holds
+// live in global memory.  e_lds = the edges kept in LDS (whole check rows).
+static bp_lds_fn bp_lds_hybrid_kernel() { return bp_lds_kernel<6, 3, true, true>; }
+static uint32_t bp_lds_hybrid_edges(const DeviceGraph &g)
+{
+    const size_t fixed = bp_lds_words(g, 0, false, 0, 0, 0) * 8;
+    return fixed >= 150 * 1024 ? 0 : (uint32_t)((150 * 1024 - fixed) / 8 / 6 * 6);
+}
+bool bp_lds_hybrid_serves(const DeviceGraph &g, int dc, int dv)
+{
+    return dc == 6 && dv == 3 && g.E < 65536 && g.n < 65535 && g.t_pack && bp_lds_bytes(g) > 150 * 1024 && bp_lds_hybrid_edges(g) >= g.E / 3;
 }
 
 // smallest LDS footprint of a workgroup (no graph copies)
@@ -3592,23 +3616,46 @@ static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_
     return best;
 }
 
-uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv) { return bp_lds_shape(g, dc, dv).workgroups; }
+static BpLdsShape bp_lds_hybrid_shape(const DeviceGraph &g)
+{
+    BpLdsShape sh{0, 0, switches().bp_lds_threads ? switches().bp_lds_threads : BPL_MAX_THREADS, bp_lds_words(g, 0, false, 0, 0, bp_lds_hybrid_edges(g)) * 8};
+    int fit = 0;
+    const void *fn = (const void *)bp_lds_hybrid_kernel();
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fn, (int)sh.threads, sh.lds) == hipSuccess && fit >= 1)
+        sh.workgroups = device_cu_count();
+    return sh;
+}
+
+uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv)
+{
+    return bp_lds_serves(g, dc) ? bp_lds_shape(g, dc, dv).workgroups : bp_lds_hybrid_serves(g, dc, dv) ? bp_lds_hybrid_shape(g).workgroups : 0;
+}
+
+// scratch of the LDS form in a.msg: per workgroup the saved state of the period test (E words) and, hybrid form, the messages beyond LDS
+size_t bp_lds_workspace_bytes(const DeviceGraph &g, int dc, int dv)
+{
+    const size_t el = bp_lds_serves(g, dc) ? g.E : bp_lds_hybrid_edges(g);
+    return (size_t)bp_lds_workgroups(g, dc, dv) * (2 * (size_t)g.E - el) * 8;
+}
 
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st)
 {
     if (!a.n_shots) return hipSuccess;
     if (!bp_lds_kernel_for(dc, dv) || a.post_out || a.chk_out) return hipErrorInvalidValue;
     const bool logical = a.test == TEST_LOGICAL && a.l_rows;
-    const BpLdsShape sh = bp_lds_shape(g, dc, dv, logical ? a.l_rows : 0, logical ? a.l_nnz : 0);
+    const bool hybrid = !bp_lds_serves(g, dc);
+    if (hybrid && !bp_lds_hybrid_serves(g, dc, dv)) return hipErrorInvalidValue;
+    const BpLdsShape sh = hybrid ? bp_lds_hybrid_shape(g) : bp_lds_shape(g, dc, dv, logical ? a.l_rows : 0, logical ? a.l_nnz : 0);
     if (!sh.workgroups) return hipErrorInvalidValue;
-    const bp_lds_fn k = bp_lds_kernel_for(dc, dv, sh.threads != BPL_THREADS);
+    const bp_lds_fn k = hybrid ? bp_lds_hybrid_kernel() : bp_lds_kernel_for(dc, dv, sh.threads != BPL_THREADS);
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
     if (e != hipSuccess) return e;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
     if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups of %u threads\n", sh.lds, sh.copies, grid, sh.threads);
     g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : dc == 3 ? "bp_lds_kernel<3>" : "bp_lds_kernel<0>";
-    hipLaunchKernelGGL(k, dim3(grid), dim3(sh.threads), sh.lds, st, g, a, sh.copies);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(sh.threads), sh.lds, st, g, a, sh.copies, hybrid ? bp_lds_hybrid_edges(g) : g.E);
     return hipGetLastError();
 }
 

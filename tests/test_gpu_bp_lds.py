@@ -137,6 +137,37 @@ def test_lds_workgroup_sizes_change_nothing(monkeypatch):
     assert all(_same(res[0], r) for r in res[1:])
 
 
+def test_lds_hybrid_form_on_the_headline_code(monkeypatch):
+    """C2 ((3,6)-regular n = 10,000: 240 KB of messages per shot) does not fit a CU's LDS; the hybrid form keeps the
+    messages of the first 19,000-odd edges in LDS and the rest in the workgroup's piece of global memory.  Same
+    arithmetic, same order: corrections, iteration counts, decoded words, counters and flags against the persistent
+    kernel bit for bit, and it is what a plain call takes."""
+    code = LinearCode.random_regular_code(10000, 5000, 3, 6, seed=1)
+    oc = oracle_code(code)
+    for p, shots, cap in ((0.02, 600, 100), (0.06, 300, 12)):
+        words = np.stack([orc.sample_bsc_words(21, i, p, 10000) for i in range(shots)])
+        syn = np.stack([oc.syndrome_words(words[i]) for i in range(shots)])
+
+        def run():
+            dec = BpDecoder(code, p, cap)
+            dc_, di = dev_u64(words.shape), dev_u32((shots,))
+            dec.correction_for_batch(shots, to_dev_u64(syn), dc_, di)
+            do, dj = dev_u64(words.shape), dev_u32((shots,))
+            dec.decode_batch(shots, to_dev_u64(words), do, dj)
+            flags = dev_u8((3000,))
+            cnt = dec.mc_run(p, 2024, 50, 3000, flags)
+            return host_u64(dc_), host_u32(di), host_u64(do), host_u32(dj), cnt, flags.cpu().numpy()
+
+        out = _forms(monkeypatch, run, forms=("lds", "persistent"))
+        assert _same(out["lds"], out["persistent"]), p
+        dflt = run()
+        assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel") and _same(dflt, out["lds"])
+        for i in range(0, shots, 97):   # and the oracle on a sample
+            c, it, _ = oc.bp_correction_for(p, cap, syn[i])
+            if (out["lds"][0][i] == c).all():
+                assert out["lds"][1][i] == it
+
+
 def test_lds_mc_counters_flags_and_split(monkeypatch):
     code = LinearCode.random_regular_code(1200, 900, 3, 4, seed=1)
 
@@ -165,8 +196,12 @@ def test_lds_is_the_default_where_it_serves_and_css_agrees(monkeypatch):
     dec = BpDecoder(code, 0.02, 100)
     dec.mc_run(0.02, 1, 0, 4096)
     assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
-    # a code whose messages do not fit (C2: 240 KB per shot) keeps the other forms
+    # a code whose messages do not fit (C2: 240 KB per shot) takes the hybrid form of the kernel (bit degree 3, check
+    # degree 6 only); a (4,8)-regular code of that size keeps the other forms
     big = BpDecoder(LinearCode.random_regular_code(10000, 5000, 3, 6, seed=1), 0.02, 100)
+    big.mc_run(0.02, 1, 0, 256)
+    assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+    big = BpDecoder(LinearCode.random_regular_code(8000, 4000, 4, 8, seed=1), 0.02, 100)
     big.mc_run(0.02, 1, 0, 256)
     assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
     # CSS: hypergraph product of the (3,4)-regular n = 20 code with itself (the css_decoding example), X and Z halves
