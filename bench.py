@@ -92,6 +92,20 @@ def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None):
     neither is priced).  reference_bytes: the same figure on the iterations the counters report, i.e. what
     belief_propagation.rs:23-30 runs for these shots."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
+    if kernel.startswith("bp_lds_kernel") and "hybrid" in kernel:
+        # one workgroup per CU holds a shot: 158 KB of its messages in LDS, the rest in its own piece of global memory,
+        # which stays in L2; HBM sees the graph, the outputs and what L2 evicts
+        ratio = replayed_ratio(pmc)
+        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "traffic": None if ratio is None else ratio * alg_bytes,
+               "traffic_source": None if ratio is None else "%s: measured traffic / algorithmic ratio x this run's algorithmic bytes "
+                                                            "(replayed, not a counter of this run)" % pmc,
+               "note": "hybrid LDS form: of the 32*E bytes per shot-iteration of SURVEY.md 8(d) about two thirds are LDS traffic and one "
+                       "third L2 traffic; frac is that equivalent rate over the HBM peak, on the iterations of message arithmetic "
+                       "that were run (a shot's first iteration comes from a table)"}
+        if reference_bytes is not None:
+            out["frac_on_reference_iterations"] = reference_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return out
     if kernel.startswith("bp_lds_kernel"):
         # a shot's messages live in LDS: the algorithmic bytes never reach HBM, the figure is an equivalent rate
         out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
@@ -158,7 +172,7 @@ def bp_line(code, shots=1 << 23):
             "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
             "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, BP_PMC, kernel)}
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, BP_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges())}
 
 
 def bp_c1_line(shots=1 << 22):

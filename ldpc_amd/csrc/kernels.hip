@@ -2228,6 +2228,10 @@ constexpr uint32_t BPL_TABLE_WORDS = 4 * 16 * 4 + 5 * 16;
 #ifndef BPL_SK
 #define BPL_SK true                     // polynomial constants built at their use by scalar moves (bp_math.hpp)
 #endif
+#ifndef BPL_HYB_WAVES_PER_SIMD
+#define BPL_HYB_WAVES_PER_SIMD 7        // (the hybrid form runs one workgroup of 16 waves per CU and could have 128 registers per lane:
+                                        // measured 531 against 524.5 ms per 2^20 shots of C2 with 72)
+#endif
 #ifndef BPL_WAVES_PER_SIMD
 #define BPL_WAVES_PER_SIMD 7            // register budget: 72 per lane, so that seven four-wave workgroups fit a CU when their LDS does
                                         // (with five-wave workgroups, CSS example / C1 ms per 2^22 shots: 4 waves 225 / 102 and 5 waves 167 / 103 with the
@@ -2268,7 +2272,7 @@ __device__ inline uint32_t bpl_lane()
 
 // DV: every bit has exactly DV checks (> 0), at most -DV (< 0), or any number (0)
 template <int DC, int DV, bool WIDE, bool HYB = false>
-__global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies, uint32_t e_lds)
+__global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB_WAVES_PER_SIMD : BPL_WAVES_PER_SIMD) void bp_lds_kernel(DeviceGraph g, BpArgs a, uint32_t copies, uint32_t e_lds)
 {
     extern __shared__ uint64_t lds[];
     const uint32_t tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (the phases of a shot take their own, BPL_FRESH)
@@ -3316,6 +3320,7 @@ Switches read_switches()
         s.bp_handoff = (uint32_t)std::strtoul(e, nullptr, 10);
     }
     s.bp_profile = std::getenv("LDPC_HIP_BP_PROFILE") != nullptr;
+    if (const char *e = std::getenv("LDPC_HIP_BP_HYB_KB")) s.bp_hyb_kb = (uint32_t)std::max(8, std::min(158, std::atoi(e)));
     if (const char *e = std::getenv("LDPC_HIP_BP_LDS_THREADS")) s.bp_lds_threads = (uint32_t)std::max(64, std::min(1024, std::atoi(e))) / 64 * 64;
     s.bp_stream_skew = std::getenv("LDPC_HIP_BP_STREAM_SKEW") != nullptr;
     if (const char *e = std::getenv("LDPC_HIP_BP_TAIL_BURST")) s.bp_tail_burst = std::max(1, std::atoi(e));
@@ -3536,12 +3541,12 @@ static bp_lds_fn bp_lds_kernel_for(int dc, int dv, bool wide = false)
 static bp_lds_fn bp_lds_hybrid_kernel() { return bp_lds_kernel<6, 3, true, true>; }
 static uint32_t bp_lds_hybrid_edges(const DeviceGraph &g)
 {
-    const size_t fixed = bp_lds_words(g, 0, false, 0, 0, 0) * 8;
-    return fixed >= 150 * 1024 ? 0 : (uint32_t)((150 * 1024 - fixed) / 8 / 6 * 6);
+    const size_t fixed = bp_lds_words(g, 0, false, 0, 0, 0) * 8, room = (size_t)(switches().bp_hyb_kb ? switches().bp_hyb_kb : 158) * 1024;
+    return fixed >= room ? 0 : (uint32_t)std::min<size_t>((room - fixed) / 8 / 6 * 6, g.E);
 }
 bool bp_lds_hybrid_serves(const DeviceGraph &g, int dc, int dv)
 {
-    return dc == 6 && dv == 3 && g.E < 65536 && g.n < 65535 && g.t_pack && bp_lds_bytes(g) > 150 * 1024 && bp_lds_hybrid_edges(g) >= g.E / 3;
+    return dc == 6 && dv == 3 && g.E < 65536 && g.n < 65535 && g.t_pack && bp_lds_bytes(g) > 150 * 1024 && bp_lds_hybrid_edges(g) >= g.E / 8;
 }
 
 // smallest LDS footprint of a workgroup (no graph copies)
@@ -3623,7 +3628,7 @@ static BpLdsShape bp_lds_hybrid_shape(const DeviceGraph &g)
     const void *fn = (const void *)bp_lds_hybrid_kernel();
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fn, (int)sh.threads, sh.lds) == hipSuccess && fit >= 1)
-        sh.workgroups = device_cu_count();
+        sh.workgroups = std::min((uint32_t)fit, std::max(1u, 24u / (sh.threads / 64))) * device_cu_count();
     return sh;
 }
 
@@ -3654,7 +3659,7 @@ hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, 
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.n_shots, sh.workgroups);
     if (switches().debug)
         std::fprintf(stderr, "[ldpc_hip] bp lds form: %zu B of LDS per shot (graph copies: %u), %u workgroups of %u threads\n", sh.lds, sh.copies, grid, sh.threads);
-    g_kernel_name = dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : dc == 3 ? "bp_lds_kernel<3>" : "bp_lds_kernel<0>";
+    g_kernel_name = hybrid ? "bp_lds_kernel<6,3> (hybrid: messages in LDS and L2)" : dc == 4 ? "bp_lds_kernel<4>" : dc == 6 ? "bp_lds_kernel<6>" : dc == 7 ? "bp_lds_kernel<7>" : dc == 3 ? "bp_lds_kernel<3>" : "bp_lds_kernel<0>";
     hipLaunchKernelGGL(k, dim3(grid), dim3(sh.threads), sh.lds, st, g, a, sh.copies, hybrid ? bp_lds_hybrid_edges(g) : g.E);
     return hipGetLastError();
 }

@@ -26,6 +26,7 @@ struct Switches {
     bool bp_handoff_set = false;      // LDPC_HIP_BP_HANDOFF given
     uint32_t bp_handoff = 16;
     bool bp_profile = false;          // LDPC_HIP_BP_PROFILE
+    uint32_t bp_hyb_kb = 0;           // LDPC_HIP_BP_HYB_KB (hybrid form: KB of LDS per workgroup; 0: 150)
     uint32_t bp_lds_threads = 0;      // LDPC_HIP_BP_LDS_THREADS (bp_lds_kernel's workgroup size; 0: chosen by bp_lds_shape)
     bool bp_stream_skew = false;      // LDPC_HIP_BP_STREAM_SKEW
     int bp_tail_burst = 0;            // LDPC_HIP_BP_TAIL_BURST (0: unset)

@@ -76,8 +76,8 @@ def bp(sub, name, kernel, edges, label):
                  "valu_busy": d["valu_pipe_busy"]}
 
 
-bp("bp", "bp", "bp_kernel<6, 3>", 30000, "python3 scripts/bp_one.py c2 8388608 0.02")
+bp("bp", "bp", "bp_lds_kernel<6, 3, true, true>", 30000, "python3 scripts/bp_one.py c2 8388608 0.02")
 bp("c5", "bp_c5", "bps_iterate", 3000000, "python3 scripts/bp_one.py c5 70656 0.02")
-bp("css", "css", "bp_lds_kernel<7, -4>", 2100, "python3 scripts/css_one.py 8388608")
-bp("c1", "bp_c1", "bp_lds_kernel<4, 3>", 3600, "python3 scripts/bp_one.py c1 4194304 0.02")
+bp("css", "css", "bp_lds_kernel<7, -4,", 2100, "python3 scripts/css_one.py 8388608")
+bp("c1", "bp_c1", "bp_lds_kernel<4, 3,", 3600, "python3 scripts/bp_one.py c1 4194304 0.02")
 print(json.dumps(out, indent=1))
