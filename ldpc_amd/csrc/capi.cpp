@@ -571,7 +571,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     // message outputs stay with the forms that keep both message arrays.  LDPC_HIP_BP_PATH = "lds" / "hbm" force and
     // forbid it.
     const bool lds_form = !r.post_out && !r.chk_out && ((bp_lds_serves(g, dec->reg_dc) && (switches().bp_path == 3 || switches().bp_path == 0)) ||
-                                                        (bp_lds_hybrid_serves(g, dec->reg_dc, dec->reg_dv) && (switches().bp_path == 3 || switches().bp_path == 0)));
+                                                        (bp_lds_hybrid_serves(g, dec->reg_dc, dec->reg_dv) && (switches().bp_path == 3 || (switches().bp_path == 0 && bp_lds_hybrid_pays(g, dec->reg_dc, dec->reg_dv)))));
     if (lds_form) {
         stream = false;
         groups = 0;

@@ -3548,6 +3548,10 @@ bool bp_lds_hybrid_serves(const DeviceGraph &g, int dc, int dv)
 {
     return dc == 6 && dv == 3 && g.E < 65536 && g.n < 65535 && g.t_pack && bp_lds_bytes(g) > 150 * 1024 && bp_lds_hybrid_edges(g) >= g.E / 8;
 }
+// ... and is ahead of bp_kernel: while LDS holds at least half of a shot's messages (the pieces in global memory stay in
+// L2).  2^19 shots, (3,6)-regular, bp_kernel / hybrid ms: E = 24,000 292 / 198, 30,000 366 / 263, 36,000 441 / 358,
+// 42,000 525 / 571, 48,000 605 / 873, 60,000 764 / 1456 (scripts/bp_hyb_reach.py).
+bool bp_lds_hybrid_pays(const DeviceGraph &g, int dc, int dv) { return bp_lds_hybrid_serves(g, dc, dv) && 2 * (uint64_t)bp_lds_hybrid_edges(g) >= g.E; }
 
 // smallest LDS footprint of a workgroup (no graph copies)
 size_t bp_lds_bytes(const DeviceGraph &g) { return bp_lds_words(g, 0, false, 0, 0) * 8; }

@@ -179,10 +179,11 @@ hipError_t launch_bp(const DeviceGraph &g, const BpArgs &a, uint32_t groups, uin
 // counters[FAILURES] += #{flags != 0}, [XFAIL] += #{flags & 1}, [ZFAIL] += #{flags & 2}
 uint32_t bp_resident_groups(uint32_t waves, int dc, int dv);
 size_t bp_lds_bytes(const DeviceGraph &g);
-bool bp_lds_serves(const DeviceGraph &g, int dc);   // the LDS-resident BP form holds this code (regular checks, messages within 64 KiB)
-bool bp_lds_hybrid_serves(const DeviceGraph &g, int dc, int dv);   // (experiment: messages partly in LDS, partly in L2-resident global memory)
-size_t bp_lds_workspace_bytes(const DeviceGraph &g, int dc, int dv);
-uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv);   // its grid; a.msg = that many x E u64 of scratch (or null)
+bool bp_lds_serves(const DeviceGraph &g, int dc);   // the LDS-resident BP form holds this code (a shot's messages and words within 150 KB)
+bool bp_lds_hybrid_serves(const DeviceGraph &g, int dc, int dv);   // hybrid form (messages partly in LDS, partly in L2-resident global memory) can run it
+bool bp_lds_hybrid_pays(const DeviceGraph &g, int dc, int dv);     // ... and measured ahead of bp_kernel (LDS holds half of a shot or more)
+size_t bp_lds_workspace_bytes(const DeviceGraph &g, int dc, int dv);   // a.msg of either form
+uint32_t bp_lds_workgroups(const DeviceGraph &g, int dc, int dv);   // its grid
 hipError_t launch_bp_lds(const DeviceGraph &g, const BpArgs &a, int dc, int dv, hipStream_t st);
 // test probe: out[i] = tanh(in[i]/2) (kind 0) or log1p(in[i]) (kind 1) with the BP kernel's own routines
 hipError_t launch_bp_math_probe(int kind, uint64_t n, const double *d_in, double *d_out, hipStream_t st);

@@ -204,6 +204,10 @@ def test_lds_is_the_default_where_it_serves_and_css_agrees(monkeypatch):
     big = BpDecoder(LinearCode.random_regular_code(8000, 4000, 4, 8, seed=1), 0.02, 100)
     big.mc_run(0.02, 1, 0, 256)
     assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+    # ... and so does a (3,6)-regular code of which LDS would hold less than half a shot (measured behind bp_kernel)
+    big = BpDecoder(LinearCode.random_regular_code(16000, 8000, 3, 6, seed=1), 0.02, 100)
+    big.mc_run(0.02, 1, 0, 256)
+    assert not ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
     # CSS: hypergraph product of the (3,4)-regular n = 20 code with itself (the css_decoding example), X and Z halves
     css = CssCode.hypergraph_product(LinearCode.random_regular_code(20, 15, 3, 4, seed=1), LinearCode.random_regular_code(20, 15, 3, 4, seed=1))
 
