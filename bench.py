@@ -41,22 +41,35 @@ CODE_SEED, NOISE_SEED = 1, 2024
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(code, budget_s=25.0):
+def _timed_sample(run, threads, budget_s, cap):
+    """run(n_shots, nthreads) -> counters, on a sample sized to about budget_s seconds of wall time (at least `threads`
+    shots, at most `cap`).  Returns (shots, seconds, counters)."""
+    run(threads, threads)                                      # warm the thread pool / page the tables in
+    t0 = time.perf_counter()
+    run(4 * threads, threads)
+    per_shot = max(time.perf_counter() - t0, 1e-4) / (4 * threads)
+    shots = int(max(threads, min(cap, budget_s / per_shot)))
+    t0 = time.perf_counter()
+    cnt = run(shots, threads)
+    return shots, time.perf_counter() - t0, cnt
+
+
+def _host_threads():
+    from oracle import oracle as orc
+    return max(1, min(16, orc.max_threads(), os.cpu_count() or 1))
+
+
+def cpu_baseline(code, budget_s=9.0):
     """The oracle's restatement of FlipDecoder::decode as written in the reference
     (flip.rs:21-43: rescan from bit 0 and a full H*e_bit per flip), timed on this
-    host on a bounded sample of the same workload."""
+    host on a bounded sample of the same workload: all host threads the box gives a GPU (16) and one thread
+    (SURVEY.md 8(d))."""
     from oracle import oracle as orc
     ptr, idx = code.csr()
     oc = orc.Code(code.len(), ptr=ptr.astype(np.int64), idx=idx.astype(np.uint32))
-    threads = max(1, min(16, orc.max_threads(), os.cpu_count() or 1))
-    oc.mc_flip(P, NOISE_SEED, 0, threads, reference_style=True, nthreads=threads)      # warm the thread pool
-    t0 = time.perf_counter()
-    oc.mc_flip(P, NOISE_SEED, 0, 8 * threads, reference_style=True, nthreads=threads)
-    per_shot = max(time.perf_counter() - t0, 1e-3) / (8 * threads)          # wall seconds per shot, all threads busy
-    shots = int(max(threads, min(200000, budget_s / per_shot)))
-    t0 = time.perf_counter()
-    cnt = oc.mc_flip(P, NOISE_SEED, 0, shots, reference_style=True, nthreads=threads)
-    dt = time.perf_counter() - t0
+    threads = _host_threads()
+    shots, dt, cnt = _timed_sample(lambda n, t: oc.mc_flip(P, NOISE_SEED, 0, n, reference_style=True, nthreads=t), threads, budget_s, 200000)
+    shots1, dt1, _ = _timed_sample(lambda n, t: oc.mc_flip(P, NOISE_SEED, 0, n, reference_style=True, nthreads=t), 1, 2.0, 20000)
     # the same decoder with incremental bookkeeping (not how the reference does it), for context
     t0 = time.perf_counter()
     fast_shots = 256 * threads
@@ -67,8 +80,41 @@ def cpu_baseline(code, budget_s=25.0):
         "sample": "%d shots of the bench workload ((3,6) n=10000, p=0.02, noise_seed=%d), reference-style "
                   "restatement of flip.rs:21-43 in C, %d OpenMP threads over shots, %.1f s" % (shots, NOISE_SEED, threads, dt),
         "failures_in_sample": int(cnt[1]),
+        "one_thread": {"value": shots1 / dt1, "unit": "shots/s", "cores": 1, "sample": "%d shots, %.1f s" % (shots1, dt1)},
         "incremental_variant_shots_per_s": fast_shots / dt_fast,
     }, cnt
+
+
+def cpu_baseline_bp(code, p, what, budget_s=3.0):
+    """The oracle's restatement of BpDecoder (belief_propagation.rs:23-30, 100-180: two f64 arrays rebuilt per shot,
+    glibc tanh / ln_1p, the full stop test per iteration) on a bounded sample of the same Monte-Carlo workload."""
+    from oracle import oracle as orc
+    ptr, idx = code.csr()
+    oc = orc.Code(code.len(), ptr=ptr.astype(np.int64), idx=idx.astype(np.uint32))
+    threads = _host_threads()
+    shots, dt, cnt = _timed_sample(lambda n, t: oc.mc_bp(p, 100, NOISE_SEED, 0, n, nthreads=t), threads, budget_s, 1 << 20)
+    shots1, dt1, _ = _timed_sample(lambda n, t: oc.mc_bp(p, 100, NOISE_SEED, 0, n, nthreads=t), 1, 1.0, 1 << 16)
+    return {"value": shots / dt, "unit": "shots/s", "cores": threads, "kind": "port",
+            "sample": "%d shots of %s, restatement of belief_propagation.rs in C (f64, glibc), %d OpenMP threads over shots, %.1f s"
+                      % (shots, what, threads, dt),
+            "iterations_per_shot_in_sample": int(cnt[4]) / shots, "failures_in_sample": int(cnt[1]),
+            "one_thread": {"value": shots1 / dt1, "unit": "shots/s", "cores": 1, "sample": "%d shots, %.1f s" % (shots1, dt1)}}
+
+
+def cpu_baseline_css(css, p, budget_s=3.0):
+    """examples/css_decoding.rs:14-21 as the oracle restates it (depolarizing sample, two BP decodes, has_stabilizer),
+    on a bounded sample."""
+    from oracle import oracle as orc
+    mats = [css.x_stabs_binary(), css.z_stabs_binary(), css.x_logicals_binary(), css.z_logicals_binary()]
+    o = [orc.Code(m.len(), rows=m.parity_check_matrix()) for m in mats]
+    threads = _host_threads()
+    run = lambda n, t: orc.mc_css_bp(o[0], o[1], o[2], o[3], p, 100, NOISE_SEED, 0, n, nthreads=t)
+    shots, dt, cnt = _timed_sample(run, threads, budget_s, 1 << 20)
+    shots1, dt1, _ = _timed_sample(run, 1, 1.0, 1 << 16)
+    return {"value": shots / dt, "unit": "shots/s", "cores": threads, "kind": "port",
+            "sample": "%d shots of configs[2] (css_decoding.rs loop body restated in C), %d OpenMP threads over shots, %.1f s" % (shots, threads, dt),
+            "logical_failures_in_sample": int(cnt[1]),
+            "one_thread": {"value": shots1 / dt1, "unit": "shots/s", "cores": 1, "sample": "%d shots, %.1f s" % (shots1, dt1)}}
 
 
 FLIP_PMC = "profiles/r02_flip_pmc.json"

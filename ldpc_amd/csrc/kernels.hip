@@ -1240,6 +1240,13 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
     }
     fs2 |= half_row_or_u32(contrib);
     nfl += one;
+    // (issue-slot probes: what ten more instructions of either kind cost a pass, profiles/README.md round 3)
+    if (SV == 1) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+    if (SV == 2) {
+        uint32_t t_ = gl;
+        asm volatile("v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n"
+                     "v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0\n v_add_u32 %0, 1, %0" : "+v"(t_));
+    }
     wave_order();
     if (STAMP) {
         uint32_t f = fs2;
@@ -1247,6 +1254,109 @@ __device__ inline void flip3_step(const char *nb_base, uint32_t dummy_row, char 
         const unsigned long long t4 = __builtin_amdgcn_s_memtime();
         stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3;
     }
+}
+
+// 32-bit LDS loads at a byte address kept in a register (the same address feeds the asm blocks below)
+__device__ inline uint32_t lds_ld32(uint32_t addr) { return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr; }
+__device__ inline uint64_t lds_ld64(uint32_t addr) { return *(const __attribute__((address_space(3))) uint64_t *)(uintptr_t)addr; }
+
+// The pass of flip3_step with the wave's own instruction stream cut down (round 3: ten more instructions in a pass,
+// scalar or vector, cost it 3.6 - 4.1 %, i.e. a pass is mostly the wave issuing its ~140 instructions at one per
+// 4.5 - 5 cycles; profiles/README.md).  Same decisions, fewer instructions:
+//   * no `found` predicate: an idle group reads a zeroed window (Fz_addr below names one), finds nothing, and the
+//     minimum with the spare row's index turns "nothing" into the spare row; fs2 == 0 scans the LAST window, which
+//     is empty like all the others then;
+//   * the three syndrome toggles and the log entry of the group's first lane, and the two masked mask writes, run
+//     under an exec mask set by hand (no branch around them: with eight shots per wave the branches were always taken);
+//   * a slot is evaluated from all three of its checks at once, and everything that does not need the syndrome words
+//     (mask word address, mask bit, window bit, the record's flag) is computed while they are on their way;
+//   * no per-pass watchdog counter in vector registers (the caller bounds the loop with a scalar budget).
+// Sg_addr / Fg_addr: LDS byte addresses of the group's syndrome and mask (Fg_addr: of a zeroed 64-byte block minus
+// wlast * 64 for a group without a shot); wlast = windows - 1.
+__device__ inline void flip3_step_v2(const char *nb_base, uint32_t dummy_row, uint32_t wlast, uint32_t Sg_addr, uint32_t Fg_addr,
+                                     uint32_t Fg_lane, const char *log_base, uint32_t log_off, uint32_t gl, uint32_t &fs2, uint32_t &nfl)
+{
+    uint32_t w2;
+    asm("v_ffbl_b32 %0, %1" : "=v"(w2) : "v"(fs2));
+    w2 = w2 < wlast ? w2 : wlast;
+    const uint64_t x = lds_ld64(Fg_lane + (w2 << 6));   // Fg_lane = Fg_addr + 8 gl
+    const uint32_t fs2r = fs2 & (fs2 - 1);        // the summary with the scanned window retired
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint32_t clo, chi;
+    asm("v_ffbl_b32 %0, %1" : "=v"(clo) : "v"(lo));
+    asm("v_ffbl_b32 %0, %1" : "=v"(chi) : "v"(hi));
+    clo |= gl << 6;
+    chi |= (gl << 6) | 32u;
+    const uint32_t c = clo < chi ? clo : chi;
+    const uint32_t mpos = half_row_min2_u32(c);
+    const uint32_t cand = (w2 << 9) | mpos;       // (all ones when the window is empty)
+    const uint32_t b = cand < dummy_row ? cand : dummy_row;
+    const uint32_t roff = (b << 8) + gl * 32u;
+    const uint4 r0 = *(const uint4 *)(nb_base + roff), r1 = *(const uint4 *)(nb_base + roff + 16);
+    // while the row is on its way: the window is empty, or the bit about to be flipped is its only one -> retire it
+    const uint32_t inwin = half_row_add_u32((uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi));
+    const uint32_t keep = inwin <= 1 ? fs2r : fs2;
+    const uint32_t one = b < dummy_row ? 1u : 0u;
+    const uint32_t log_at = log_off + nfl * 2u;
+    nfl += one;
+    // slot 0 of the group's first lane is b itself: syndrome ^= H e_b (flip.rs:28-29); output ^= e_b (flip.rs:30) is
+    // deferred: the flip is logged
+    const uint32_t a0 = Sg_addr + (r0.y >> 16), a1 = Sg_addr + (r0.z >> 16), a2 = Sg_addr + (r0.w >> 16);
+    const uint32_t a3 = Sg_addr + (r1.y >> 16), a4 = Sg_addr + (r1.z >> 16), a5 = Sg_addr + (r1.w >> 16);
+    {
+        const uint32_t d0 = one << (r0.y & 31), d1 = one << (r0.z & 31), d2 = one << (r0.w & 31);
+        uint64_t sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_and_b64 exec, exec, %[l0]\n\t"
+                     "ds_xor_b32 %[a0], %[d0]\n\t"
+                     "ds_xor_b32 %[a1], %[d1]\n\t"
+                     "ds_xor_b32 %[a2], %[d2]\n\t"
+                     "global_store_short %[la], %[b], %[lb]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv)
+                     : [l0] "s"(0x0101010101010101ull), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2),
+                       [la] "v"(log_at), [b] "v"(b), [lb] "s"(log_base)
+                     : "memory");
+    }
+    // both slots of the lane against the new syndrome: six words in one LDS round trip
+    uint32_t w0 = lds_ld32(a0), w1 = lds_ld32(a1), w2s = lds_ld32(a2), w3 = lds_ld32(a3), w4 = lds_ld32(a4), w5 = lds_ld32(a5);
+    // (on the way: where and what a slot would write)
+    uint32_t fa0 = Fg_addr + (r0.x >> 16), fa1 = Fg_addr + (r1.x >> 16);
+    uint32_t m0 = one << (r0.x & 31), m1 = one << (r1.x & 31);
+    uint32_t wb0 = 1u << (r0.x >> 22), wb1 = 1u << (r1.x >> 22);
+    uint64_t gm0, gm1;   // lane masks: the record is flagged
+    {
+        const uint32_t g0 = r0.x & 0x100u, g1 = r1.x & 0x100u;
+        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(gm0) : "v"(g0));
+        asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(gm1) : "v"(g1));
+    }
+    asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(m0), "+v"(m1), "+v"(wb0), "+v"(wb1), "+s"(gm0), "+s"(gm1));
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2s), "+v"(w3), "+v"(w4), "+v"(w5));
+    // One of a neighbour's checks (word 3 of its record) changed by this flip, so its mask bit changes only if the
+    // other two hold exactly one unsatisfied check; the record's flag covers the slots for which that does not hold
+    // (b itself, doubly connected bits).  flip.rs:41 for three checks: flippable iff two or more are unsatisfied.
+    const uint32_t x0 = bit_of(w0, r0.y), y0 = bit_of(w1, r0.z), t0 = x0 + y0 + bit_of(w2s, r0.w);
+    const uint32_t x1 = bit_of(w3, r1.y), y1 = bit_of(w4, r1.z), t1 = x1 + y1 + bit_of(w5, r1.w);
+    const uint32_t v0 = t0 >= 2 ? m0 : 0u, v1 = t1 >= 2 ? m1 : 0u;
+    {
+        uint64_t sv, c0, c1;
+        asm volatile("v_cmp_ne_u32_e64 %[c0], %[x0], %[y0]\n\t"
+                     "v_cmp_ne_u32_e64 %[c1], %[x1], %[y1]\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_or_b64 %[c0], %[c0], %[g0]\n\t"
+                     "s_or_b64 %[c1], %[c1], %[g1]\n\t"
+                     "s_and_b64 exec, %[sv], %[c0]\n\t"
+                     "ds_mskor_b32 %[fa0], %[m0], %[v0]\n\t"
+                     "s_and_b64 exec, %[sv], %[c1]\n\t"
+                     "ds_mskor_b32 %[fa1], %[m1], %[v1]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv), [c0] "=&s"(c0), [c1] "=&s"(c1)
+                     : [g0] "s"(gm0), [g1] "s"(gm1), [x0] "v"(x0), [y0] "v"(y0), [x1] "v"(x1), [y1] "v"(y1), [fa0] "v"(fa0), [fa1] "v"(fa1),
+                       [m0] "v"(m0), [m1] "v"(m1), [v0] "v"(v0), [v1] "v"(v1)
+                     : "memory");
+    }
+    const uint32_t contrib = (t0 >= 2 ? wb0 : 0u) | (t1 >= 2 ? wb1 : 0u);
+    fs2 = keep | half_row_or_u32(contrib);
 }
 
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
@@ -1349,7 +1459,7 @@ template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGr
 // workgroup-scope release, taken with LDS compare-and-swap.
 // ---------------------------------------------------------------------------
 constexpr uint32_t F4_FREE = 0, F4_HELD = 1, F4_READY = 2, F4_RUNNING = 3, F4_DONE = 4;
-constexpr uint32_t F4_MAX_SLOTS = 128;
+constexpr uint32_t F4_MAX_SLOTS = 112;
 constexpr uint32_t F4_LOGS = F4_MAX_SLOTS + 16;   // flip logs / parked words per block in HBM scratch
 
 struct Flip4Ctl {
@@ -1362,6 +1472,7 @@ struct Flip4Ctl {
     uint32_t n_output;               // shots written out
     uint32_t abort;                  // watchdog: a wave gave up waiting (never in a correct run)
     uint32_t cnt[16];                // per service wave: list fill counter
+    uint32_t zero[16];               // an empty mask window: what a flip group without a shot scans (flip3_step_v2)
 };
 
 __host__ __device__ constexpr uint32_t flip4_hdr_words(uint32_t list_cap, uint32_t helpers)
@@ -1503,8 +1614,12 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     }
     // ===================================================================== flip wave
     if (a.max_flips == 1) __builtin_amdgcn_s_setprio(3);   // (experiment) the serial chains win the issue arbitration
+    constexpr bool V2 = SV == 3;
     uint32_t slot = NONE, fs2 = 0, nfl = 0, idle = 0, steps = 0;
     char *Sg = (char *)state, *Fg = Sg + (size_t)Sw * 8;
+    // (V2: LDS byte addresses; a group without a shot scans the zeroed window of the control block)
+    const uint32_t wlast = nbt.windows - 1, Fz_addr = lds_addr_of(ctl->zero) - wlast * 64u;
+    uint32_t Sg_addr = lds_addr_of(state), Fg_addr = Fz_addr;
     // flip logs as byte offsets from the block's first one (uniform base + 32-bit offset: F4_LOGS logs of < 2^17 bytes)
     char *const log_base = (char *)log_of(0);
     const uint32_t waste = (F4_MAX_SLOTS + wave) * a.flip_log_cap * 2u;
@@ -1533,6 +1648,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
                     slot = NONE;
                     log_off = waste;
                     nfl = 0;
+                    Fg_addr = Fz_addr;
                 }
             }
             // ready slots (two status words per lane), dealt to the groups that need one in lane order
@@ -1572,6 +1688,8 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
                     nfl = 0;
                     Sg = (char *)(state + (size_t)slot * per_shot);
                     Fg = Sg + (size_t)Sw * 8;
+                    Sg_addr = lds_addr_of(Sg);
+                    Fg_addr = lds_addr_of(Fg);
                     log_off = slot * a.flip_log_cap * 2u;
                     steps = 0;
                     // (a shot with nothing to flip has fs2 == 0 and is handed back on the next pass)
@@ -1589,6 +1707,18 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
                 continue;
             }
             idle = 0;
+        }
+        if (V2) {
+            // passes until some group runs out of flips (a shot ends within step_cap passes, so a wave that runs more
+            // than that without a shot ending is stuck -- cannot happen; never spin on a bug)
+            uint32_t left = step_cap;
+            do flip3_step_v2((const char *)nbt.rec, g.n, wlast, Sg_addr, Fg_addr, Fg_addr + gl * 8u, log_base, log_off, gl, fs2, nfl);
+            while (!__ballot(fs2 == 0) && --left);
+            if (!left) {
+                if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+            }
+            continue;
         }
         flip3_step<PROF, SV>((const char *)nbt.rec, g.n, Sg, Fg, log_base, log_off, gl, fs2, nfl, p_stamp);
         if (__ballot(++steps > step_cap)) {   // cannot happen; never spin on a bug
@@ -3447,6 +3577,8 @@ static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
     case 9: return prof ? flip4_kernel<9, true> : flip4_kernel<9>;
     case 10: return flip4_kernel<10>;
     case 109: return flip4_kernel<9, false, 8, 7, 1>;
+    case 209: return flip4_kernel<9, false, 8, 7, 2>;
+    case 309: return flip4_kernel<9, false, 8, 7, 3>;
     default: return nullptr;
     }
 }

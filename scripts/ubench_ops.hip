@@ -27,7 +27,7 @@ template <int OP> __global__ __launch_bounds__(256) void op_kernel(uint32_t iter
     if (OP == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(r[i]) : "v"(k));                                    \
     if (OP == 3) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(r[i]), "v"(k) : "vcc");       \
     if (OP == 4) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r[i]) : "v"(k));                                   \
-    if (OP == 5) asm volatile("v_xor3_b32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(k));                                  \
+    if (OP == 5) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(k));                                  \
     if (OP == 6) asm volatile("v_ffbl_b32 %0, %0" : "+v"(r[i]));                                                   \
     if (OP == 7) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(r[i]) : "v"(k));                                  \
     if (OP == 8) asm volatile("v_bfe_u32 %0, %0, %1, 7" : "+v"(r[i]) : "v"(k));                                    \
@@ -57,7 +57,7 @@ int main()
     unsigned long long *cyc;
     const int blocks = 256 * 4;
     if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess || hipMalloc(&cyc, blocks * 8) != hipSuccess) return 1;
-    const char *names[16] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24", "v_xor3_b32", "v_ffbl_b32",
+    const char *names[16] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24", "v_xor_b32", "v_ffbl_b32",
                              "v_bcnt_u32_b32", "v_bfe_u32", "s_nop 1 + v_min_u32_dpp", "v_lshl_or_b32", "v_log_f32", "v_cvt_f32_u32",
                              "v_mul_hi_u32_u24", "v_lshlrev_b64", "v_mov_b32_dpp"};
     kfn fns[16] = {op_kernel<0>, op_kernel<1>, op_kernel<2>, op_kernel<3>, op_kernel<4>, op_kernel<5>, op_kernel<6>, op_kernel<7>,
