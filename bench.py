@@ -24,7 +24,6 @@ launch / reduce / print logic only, tests/test_bench_launch.py).
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -117,68 +116,100 @@ def cpu_baseline_css(css, p, budget_s=3.0):
             "one_thread": {"value": shots1 / dt1, "unit": "shots/s", "cores": 1, "sample": "%d shots, %.1f s" % (shots1, dt1)}}
 
 
-FLIP_PMC = "profiles/r02_flip_pmc.json"
-BP_PMC = "profiles/r02_bp_pmc.json"
-C5_PMC = "profiles/r02_bp_c5_pmc.json"
-CSS_PMC = "profiles/r02_css_pmc.json"
+FLIP_PMC = "profiles/r03_flip_pmc.json"
+FLIP_PIPES = "profiles/r03_flip_pipes.json"
+BP_PMC = "profiles/r03_bp_pmc.json"
+C5_PMC = "profiles/r03_bp_c5_pmc.json"
+CSS_PMC = "profiles/r03_css_pmc.json"
+C1_PMC = "profiles/r03_bp_c1_pmc.json"
+CLOCK_HZ = 2.4e9                                 # MI355X_MICROARCH.md: shader clock
+N_SIMD, N_CU = 1024, 256
+VALU_F64_PEAK = N_SIMD * CLOCK_HZ / 4 / 1e9      # G wave-instructions / s: one f64 wave-instruction per SIMD per 4 cycles
+LDS_PEAK_GBS = N_CU * 256 * CLOCK_HZ / 1e9       # MI355X_MICROARCH.md LDS: 256 B / clk / CU (ds_read_b64 / b128; 128 for b32)
 
 
-def replayed_ratio(path):
-    """traffic / algorithmic bytes of a recorded rocprofv3 PMC run of the same workload (profiles/), or None."""
+def _profile(path):
     try:
         with open(os.path.join(ROOT, path)) as f:
-            return float(json.load(f)["traffic_over_algorithmic"])
+            return json.load(f)
     except Exception:
         return None
 
 
-def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None):
+def replayed_ratio(path):
+    """traffic / algorithmic bytes of a recorded rocprofv3 PMC run of the same workload (profiles/), or None."""
+    d = _profile(path)
+    try:
+        return float(d["traffic_over_algorithmic"])
+    except Exception:
+        return None
+
+
+def lds_object(path, per_launch=False):
+    """LDS-array utilisation of the recorded PMC run of this workload (replayed): SQ_LDS_IDX_ACTIVE counts all LDS-array
+    cycles, SQ_LDS_BANK_CONFLICT the extra cycles of conflicts (MI355X_MICROARCH.md, LDS); the array moves up to 256 B per
+    cycle and CU, so `achieved` = busy fraction x that peak is an upper estimate of the bytes moved."""
+    d = _profile(path)
+    try:
+        c = d["counters_per_launch"] if per_launch else d["counters"]
+        cu_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_CU
+        busy = c["SQ_LDS_IDX_ACTIVE"] / cu_cycles
+        return {"array_busy_frac": busy, "bank_conflict_share": c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0),
+                "achieved": busy * LDS_PEAK_GBS, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                "source": "%s: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x %d CUs) (replayed, not a counter of this run)" % (path, N_CU)}
+    except Exception:
+        return None
+
+
+def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None, shots=None):
     """alg_bytes: 32 * E per shot-iteration of message arithmetic ACTUALLY RUN (ldpc_last_bp_executed_iterations: the LDS
     form serves a shot's first iteration from a table and ends a run that is found to repeat with period two early;
     neither is priced).  reference_bytes: the same figure on the iterations the counters report, i.e. what
-    belief_propagation.rs:23-30 runs for these shots."""
+    belief_propagation.rs:23-30 runs for these shots.
+    Forms that keep a shot's messages in LDS (bp_lds_kernel) are bound by f64 vector issue, not HBM: their object is
+    priced in vector wave-instructions per second against one per SIMD per four cycles, with the instructions per shot
+    replayed from the recorded PMC pass of the same workload; the HBM-equivalent rate of the 32 E bytes stays as a
+    secondary field, and `traffic` is what HBM really sees."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    if kernel.startswith("bp_lds_kernel") and "hybrid" in kernel:
-        # one workgroup per CU holds a shot: 158 KB of its messages in LDS, the rest in its own piece of global memory,
-        # which stays in L2; HBM sees the graph, the outputs and what L2 evicts
-        ratio = replayed_ratio(pmc)
-        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-               "traffic": None if ratio is None else ratio * alg_bytes,
-               "traffic_source": None if ratio is None else "%s: measured traffic / algorithmic ratio x this run's algorithmic bytes "
-                                                            "(replayed, not a counter of this run)" % pmc,
-               "note": "hybrid LDS form: of the 32*E bytes per shot-iteration of SURVEY.md 8(d) about two thirds are LDS traffic and one "
-                       "third L2 traffic; frac is that equivalent rate over the HBM peak, on the iterations of message arithmetic "
-                       "that were run (a shot's first iteration comes from a table)"}
-        if reference_bytes is not None:
-            out["frac_on_reference_iterations"] = reference_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        return out
-    if kernel.startswith("bp_lds_kernel"):
-        # a shot's messages live in LDS: the algorithmic bytes never reach HBM, the figure is an equivalent rate
-        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-               "traffic_source": None, "note": "LDS-resident form: the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic, "
-                                               "HBM sees only the graph and the outputs; frac is that equivalent rate over the HBM peak, "
-                                               "on the iterations of message arithmetic that were run"}
-        if reference_bytes is not None:
-            out["frac_on_reference_iterations"] = reference_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        return out
     ratio = replayed_ratio(pmc)
-    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None if ratio is None else ratio * alg_bytes,
-            "traffic_source": None if ratio is None else "%s: measured traffic / algorithmic ratio x this run's algorithmic bytes "
-                                                         "(replayed, not a counter of this run)" % pmc}
+    src = None if ratio is None else "%s: measured traffic / algorithmic ratio x this run's algorithmic bytes (replayed, not a counter of this run)" % pmc
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    if reference_bytes is not None:
+        hbm["frac_on_reference_iterations"] = reference_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if kernel.startswith("bp_lds_kernel"):
+        d = _profile(pmc)
+        hybrid = "hybrid" in kernel
+        out = {"bound": "valu_f64", "achieved": None, "peak": VALU_F64_PEAK, "unit": "G wave-instr/s", "frac": None,
+               "traffic": None if ratio is None else ratio * alg_bytes, "traffic_source": src,
+               "hbm_equivalent": hbm, "lds": lds_object(pmc),
+               "note": ("hybrid LDS form: about two thirds of the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic and one "
+                        "third L2 traffic (the workgroup's own piece of global memory); " if hybrid else
+                        "LDS-resident form: the 32*E bytes per shot-iteration of SURVEY.md 8(d) are LDS traffic, HBM sees the graph and the "
+                        "outputs; ") + "hbm_equivalent is that rate over the HBM peak on the iterations of message arithmetic that were run"}
+        try:
+            per_shot = d["counters"]["SQ_INSTS_VALU"] / d["shots"]
+            if shots:
+                rate = per_shot * shots / (ms * 1e-3) / 1e9
+                out.update({"achieved": rate, "frac": rate / VALU_F64_PEAK, "valu_instructions_per_shot": per_shot,
+                            "valu_source": "%s: SQ_INSTS_VALU / shots of the recorded pass x this run's shots/s (replayed)" % pmc})
+        except Exception:
+            pass
+        return out
+    out = {"bound": "hbm", "traffic": None if ratio is None else ratio * alg_bytes, "traffic_source": src}
+    out.update(hbm)
+    return out
 
 
 def flip_binder():
     """What binds the headline kernel (for the LDS-resident flip kernel the HBM fraction is small by
-    construction): the pipe utilisation of the tracked counter pass, replayed, with its source named."""
-    path = "profiles/r02_flip_pipes.json"
-    text = "not HBM: the dependent chain of a flip pass (8 flips per ~1200 cycles per wave) x the 81 shots a CU's LDS holds"
+    construction): the instruction stream of a pass, with the counters of the tracked pass replayed and their source named."""
+    text = ("not HBM: a flip wave issues the ~95 instructions of a pass (8 flips) at one per ~4.5 cycles and waits for one L2 row "
+            "and two LDS round trips; 72 of the 81 shots a CU's LDS holds are in such a pass at any time")
+    d = _profile(FLIP_PIPES)
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path)) as f:
-            d = json.load(f)
         return {"what": text, "valu_pipe_busy": d["valu_pipe_busy"], "valu_instructions_per_shot": d["valu_instructions_per_shot"],
-                "source": path + " (replayed, not a counter of this run)"}
-    except (OSError, KeyError, ValueError):
+                "source": FLIP_PIPES + " (replayed, not a counter of this run)"}
+    except Exception:
         return {"what": text, "valu_pipe_busy": None, "source": None}
 
 
@@ -186,9 +217,8 @@ def recorded_traffic(shots_per_launch):
     """HBM-side bytes per launch, NOT measured in this run: the per-shot figure of the rocprofv3 PMC passes over this
     same command (fabric read + write requests of the flip kernel, kept in FLIP_PMC) times this run's shots per
     launch.  Returns (bytes, source label); (None, None) when no profile is on record."""
+    prof = _profile(FLIP_PMC)
     try:
-        with open(os.path.join(ROOT, FLIP_PMC)) as f:
-            prof = json.load(f)
         return prof["traffic_bytes_per_shot"] * shots_per_launch, "%s x shots per launch (replayed, not a counter of this run)" % FLIP_PMC
     except Exception:
         return None, None
@@ -196,16 +226,14 @@ def recorded_traffic(shots_per_launch):
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run and relay rank 0's
-    line.  Runs before this process touches torch.cuda / HIP (a process that holds the GPU must not exec)."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    line.  Runs before this process touches torch.cuda / HIP (a process that holds the GPU must not exec).  The
+    rendezvous port is torchrun's own choice (--standalone), on 127.0.0.1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd)
 
 
-def bp_line(code, shots=1 << 23):
+def bp_line(code, shots=1 << 23, no_cpu=False):
     """Secondary measurement: the f64 BP kernel on the same code and channel (Monte-Carlo mode,
     max 100 iterations).  Algorithmic bytes = 32*E per shot-iteration."""
     import ldpc_amd
@@ -218,10 +246,11 @@ def bp_line(code, shots=1 << 23):
             "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
             "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, BP_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges())}
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, BP_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges(), shots),
+            "cpu_baseline": None if no_cpu else cpu_baseline_bp(code, P, "the same workload ((3,6) n=10000, p=0.02, BP max 100 iterations)")}
 
 
-def bp_c1_line(shots=1 << 22):
+def bp_c1_line(shots=1 << 22, no_cpu=False):
     """Secondary measurement: configs[0]'s code, (3,4)-regular n = 1200, BSC p = 0.02, BpDecoder f64 max 100 iterations:
     the LDS-resident BP form (a shot's 28.8 KB of messages in LDS, one workgroup per shot in flight)."""
     import ldpc_amd
@@ -236,11 +265,12 @@ def bp_c1_line(shots=1 << 22):
             "shots_per_s": shots / (ms * 1e-3), "kernel": kernel, "kernel_ms": ms,
             "iterations_per_shot": int(cnt[ldpc_amd.CNT_WORK]) / shots, "iterations_run_per_shot": ran / shots,
             "failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, "profiles/r02_bp_c1_pmc.json", kernel,
-                                    int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges())}
+            "roofline": bp_roofline(ran * 32 * code.num_edges(), ms, C1_PMC, kernel,
+                                    int(cnt[ldpc_amd.CNT_WORK]) * 32 * code.num_edges(), shots),
+            "cpu_baseline": None if no_cpu else cpu_baseline_bp(code, P, "configs[0] ((3,4) n=1200, p=0.02, BP max 100 iterations)", budget_s=2.0)}
 
 
-def css_line(shots=1 << 23):
+def css_line(shots=1 << 23, no_cpu=False):
     """Secondary measurement: configs[2], the CSS code of examples/css_decoding.rs (hypergraph product of a
     (3,4)-regular n = 20 code with itself: 625 qubits), depolarizing p = 0.01, CssDecoder<BpDecoder> max 100
     iterations, X and Z halves decoded independently.  Algorithmic bytes = 32 * 2100 per shot-iteration of a half."""
@@ -261,7 +291,8 @@ def css_line(shots=1 << 23):
             # states, which is found out exactly and ends them early
             "iterations_run_per_shot_both_halves": ran / shots,
             "logical_failures": int(cnt[ldpc_amd.CNT_FAILURES]),
-            "roofline": bp_roofline(ran * 32 * edges, ms, CSS_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges)}
+            "roofline": bp_roofline(ran * 32 * edges, ms, CSS_PMC, kernel, int(cnt[ldpc_amd.CNT_WORK]) * 32 * edges, shots),
+            "cpu_baseline": None if no_cpu else cpu_baseline_css(css, 0.01)}
 
 
 def bp_c5_line(shots=70656):
@@ -363,9 +394,12 @@ def main():
     t0 = time.perf_counter()
     counters = np.zeros(ldpc_amd.N_COUNTERS, dtype=np.uint64)
     kernel_ms = []
+    executed = 0            # BP step: iterations of message arithmetic actually run on this rank (rooflines are priced on them)
     for s in range(args.steps):
         counters += step(args.warmup + s)
         kernel_ms.append(1.0 if stub else ldpc_amd.last_kernel_ms())
+        if use_bp and not stub:
+            executed += ldpc_amd.last_bp_executed_iterations()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -405,49 +439,51 @@ def main():
                 "kernel": "stub" if stub else ldpc_amd.last_kernel_name(), "kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_shot": bytes_per_shot,
                 "binder": flip_binder(),
+                "lds": lds_object(FLIP_PMC, per_launch=True),
             },
+            "backend": "none" if world == 1 else backend,
+            "world_size_seen": dist.get_world_size() if world > 1 and dist.is_initialized() else 1,
             "counters": {k: int(v) for k, v in zip(ldpc_amd.COUNTER_NAMES, counters)},
         }
         if stub:
             line["data"] = "stub (no GPU step: launch / reduce / print logic only)"
             print(json.dumps(line), flush=True)
-        elif True:
-            finish_line(line, args, world, use_bp, code, counters, avg_kernel_s)
+        else:
+            finish_line(line, args, world, use_bp, code, counters, avg_kernel_s, executed)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def finish_line(line, args, world, use_bp, code, counters, avg_kernel_s):
+def finish_line(line, args, world, use_bp, code, counters, avg_kernel_s, executed):
     """Rank 0: the N = 1 extras (cpu_baseline, secondary BP / C5 / CSS objects) or the BP step's own roofline, then print."""
     import ldpc_amd
-    if True:
-        if not args.no_cpu_baseline and world == 1 and not use_bp:   # reported at N = 1 only
-            cb, _ = cpu_baseline(code)
-            line["cpu_baseline"] = cb
-        if not args.no_bp and world == 1 and not use_bp:
-            line["bp"] = bp_line(code)
-            line["bp_c5"] = bp_c5_line()
-            line["css"] = css_line()
-            line["bp_c1"] = bp_c1_line()
-        if use_bp:
-            # BP step: algorithmic bytes = 32 E per shot-iteration (SURVEY.md 8d), iterations from the all-reduced counter
-            alg = float(counters[ldpc_amd.CNT_WORK]) / world / args.steps * 32 * code.num_edges()
-            line["dtype"] = "f64"
-            line["config"]["workload"] = ("configs[1] with the BP decoder: random (3,6)-regular LDPC n=10000 m=5000 (code_seed=1), "
-                                          "BSC p=0.02, Philox noise_seed=2024, BpDecoder f64 max 100 iterations, fused "
-                                          "sample+syndrome+decode+failure test, counters only")
-            line["roofline"] = {"bound": "hbm", "achieved": alg / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": alg / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                "kernel": "bp_kernel<6,3>", "kernel_ms": avg_kernel_s * 1e3,
-                                "algorithmic_bytes_per_shot_iteration": 32 * code.num_edges()}
-            try:
-                with open(os.path.join(ROOT, BP_PMC)) as f:
-                    line["roofline"]["traffic"] = json.load(f)["traffic_over_algorithmic"] * alg
-                    line["roofline"]["traffic_source"] = "%s: measured ratio x algorithmic bytes (replayed, not a counter of this run)" % BP_PMC
-            except Exception:
-                pass
-        print(json.dumps(line), flush=True)
+    no_cpu = args.no_cpu_baseline
+    if not no_cpu and world == 1 and not use_bp:   # reported at N = 1 only
+        cb, _ = cpu_baseline(code)
+        line["cpu_baseline"] = cb
+    if not args.no_bp and world == 1 and not use_bp:
+        line["bp"] = bp_line(code, no_cpu=no_cpu)
+        line["bp_c5"] = bp_c5_line()
+        line["css"] = css_line(no_cpu=no_cpu)
+        line["bp_c1"] = bp_c1_line(no_cpu=no_cpu)
+    if use_bp:
+        # BP step: the kernel that ran names its own roofline; algorithmic bytes = 32 E per shot-iteration of message
+        # arithmetic run on rank 0 (SURVEY.md 8d), per launch; the reference's count comes from the all-reduced counter
+        E = code.num_edges()
+        kernel = ldpc_amd.last_kernel_name()
+        alg = executed / args.steps * 32.0 * E
+        ref = float(counters[ldpc_amd.CNT_WORK]) / world / args.steps * 32.0 * E
+        line["dtype"] = "f64"
+        line["config"]["workload"] = ("configs[1] with the BP decoder: random (3,6)-regular LDPC n=10000 m=5000 (code_seed=1), "
+                                      "BSC p=0.02, Philox noise_seed=2024, BpDecoder f64 max 100 iterations, fused "
+                                      "sample+syndrome+decode+failure test, counters only")
+        line["roofline"] = bp_roofline(alg, avg_kernel_s * 1e3, BP_PMC, kernel, ref, args.shots_per_step)
+        line["roofline"].update({"kernel": kernel, "kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_shot_iteration": 32 * E,
+                                 "iterations_run_per_launch_rank0": executed / args.steps})
+        if world == 1 and not no_cpu:
+            line["cpu_baseline"] = cpu_baseline_bp(code, P, "the same workload ((3,6) n=10000, p=0.02, BP max 100 iterations)")
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -3,13 +3,21 @@
 //! `GpuBpDecoder` implements `LinearDecoder`, `SyndromeDecoder<SparseBinSlice, SparseBinVec>`
 //! and `ClassicalSyndromeDecoder` (ldpc/src/decoders/mod.rs:15-23), so it drops into
 //! `CssDecoder { x, z }` exactly where `BpDecoder` sits in examples/css_decoding.rs:41-44.
-//! `GpuFlipDecoder::decode` mirrors `FlipDecoder::decode` (ldpc/src/decoders/flip.rs:21-33).
+//! `GpuFlipDecoder<Code>::decode<T>` mirrors `FlipDecoder<Code>::decode<T>` (ldpc/src/decoders/flip.rs:17-33),
+//! `GpuBinarySymmetricChannel`, `GpuDepolarizingNoise` and `GpuErasureChannel` implement `NoiseModel`
+//! (ldpc/src/noise/mod.rs:24-30): the caller's `R: Rng` supplies the 64-bit seed of the device stream.
 //!
-//! This file is not compiled in the repository's environment (no Rust toolchain there).
+//! This file is not compiled in the repository's environment (no Rust toolchain there).  Its `extern "C"` block is
+//! checked against include/ldpc_hip.h, name by name and type by type, by tests/test_rust_shim_abi.py.
+use ldpc::codes::LinearCode;
 use ldpc::decoders::{ClassicalSyndromeDecoder, LinearDecoder, SyndromeDecoder};
-use ldpc::noise::Probability;
-use sparse_bin_mat::{SparseBinMat, SparseBinSlice, SparseBinVec};
+use ldpc::noise::{NoiseModel, Probability};
+use pauli::{Pauli, PauliOperator, X, Y, Z};
+use rand::Rng;
+use sparse_bin_mat::{SparseBinMat, SparseBinSlice, SparseBinVec, SparseBinVecBase};
+use std::borrow::Borrow;
 use std::ffi::CStr;
+use std::fmt;
 use std::os::raw::{c_char, c_double, c_int};
 
 #[repr(C)]
@@ -45,6 +53,38 @@ extern "C" {
         out: *mut *mut ldpc_code,
     ) -> c_int;
     fn ldpc_code_destroy(code: *mut ldpc_code);
+    fn ldpc_code_has_codeword(
+        code: *const ldpc_code,
+        len: usize,
+        positions: *const usize,
+        n_positions: usize,
+        out: *mut c_int,
+    ) -> c_int;
+    fn ldpc_bsc_sample_error_of_length(
+        probability: c_double,
+        len: usize,
+        seed: u64,
+        shot: u64,
+        out_positions: *mut usize,
+        out_n: *mut usize,
+    ) -> c_int;
+    fn ldpc_depolarizing_sample_error_of_length(
+        probability: c_double,
+        len: usize,
+        seed: u64,
+        shot: u64,
+        out_positions: *mut usize,
+        out_paulis: *mut u8,
+        out_n: *mut usize,
+    ) -> c_int;
+    fn ldpc_erasure_sample_error_of_length(
+        probability: c_double,
+        len: usize,
+        seed: u64,
+        shot: u64,
+        out_positions: *mut usize,
+        out_n: *mut usize,
+    ) -> c_int;
     fn ldpc_flip_create(code: *const ldpc_code, out: *mut *mut ldpc_flip_decoder) -> c_int;
     fn ldpc_flip_decode(
         dec: *mut ldpc_flip_decoder,
@@ -132,9 +172,9 @@ fn check(status: c_int) {
     }
 }
 
-struct Code(*mut ldpc_code);
+struct Code_(*mut ldpc_code);
 
-impl Code {
+impl Code_ {
     fn from_matrix(matrix: &SparseBinMat) -> Self {
         let mut row_ptr = vec![0usize];
         let mut col_idx = Vec::with_capacity(matrix.number_of_ones());
@@ -152,11 +192,11 @@ impl Code {
                 &mut handle,
             )
         });
-        Code(handle)
+        Code_(handle)
     }
 }
 
-impl Drop for Code {
+impl Drop for Code_ {
     fn drop(&mut self) {
         unsafe { ldpc_code_destroy(self.0) }
     }
@@ -165,6 +205,7 @@ impl Drop for Code {
 /// Drop-in for `ldpc::decoders::BpDecoder` (belief_propagation.rs:8-12).
 pub struct GpuBpDecoder {
     handle: *mut ldpc_bp_decoder,
+    code: Code_,
     num_bits: usize,
     num_checks: usize,
 }
@@ -176,14 +217,35 @@ unsafe impl Sync for GpuBpDecoder {}
 impl GpuBpDecoder {
     /// `BpDecoder::new(&parity_mat, probability, num_iterations)` (belief_propagation.rs:36-46)
     pub fn new(parity_mat: &SparseBinMat, probability: Probability, num_iterations: usize) -> Self {
-        let code = Code::from_matrix(parity_mat);
+        let code = Code_::from_matrix(parity_mat);
         let mut handle = std::ptr::null_mut();
         check(unsafe { ldpc_bp_create(code.0, probability.value(), num_iterations, &mut handle) });
         Self {
             handle,
+            code,
             num_bits: parity_mat.number_of_columns(),
             num_checks: parity_mat.number_of_rows(),
         }
+    }
+
+    /// `BpDecoder::num_bits` (belief_propagation.rs:78-80)
+    pub fn num_bits(&self) -> usize {
+        self.num_bits
+    }
+
+    /// `BpDecoder::num_checks` (belief_propagation.rs:82-84)
+    pub fn num_checks(&self) -> usize {
+        self.num_checks
+    }
+
+    /// `BpDecoder::has_zero_syndrome` (belief_propagation.rs:86-88): `(H * vector).is_zero()`
+    pub fn has_zero_syndrome(&self, vector: SparseBinSlice) -> bool {
+        let positions = vector.as_slice();
+        let mut out: c_int = 0;
+        check(unsafe {
+            ldpc_code_has_codeword(self.code.0, vector.len(), positions.as_ptr(), positions.len(), &mut out)
+        });
+        out != 0
     }
 
     /// Whole Monte-Carlo run on device: BSC(noise) -> syndrome -> BP -> failure test.
@@ -252,26 +314,38 @@ impl LinearDecoder for GpuBpDecoder {
     }
 }
 
-/// Drop-in for `ldpc::decoders::FlipDecoder` (flip.rs:7-9).
-pub struct GpuFlipDecoder {
+/// Drop-in for `ldpc::decoders::FlipDecoder<Code>` (flip.rs:7-9): generic over how the code is held
+/// (`LinearCode`, `&LinearCode`, `Rc<LinearCode>`, ...: `Code: Borrow<LinearCode>`, flip.rs:17-19).
+pub struct GpuFlipDecoder<Code> {
+    code: Code,
     handle: *mut ldpc_flip_decoder,
     num_bits: usize,
 }
 
-unsafe impl Send for GpuFlipDecoder {}
-unsafe impl Sync for GpuFlipDecoder {}
+unsafe impl<Code: Send> Send for GpuFlipDecoder<Code> {}
+unsafe impl<Code: Sync> Sync for GpuFlipDecoder<Code> {}
 
-impl GpuFlipDecoder {
+impl<Code> GpuFlipDecoder<Code>
+where
+    Code: Borrow<LinearCode>,
+{
     /// `FlipDecoder::new(code)` (flip.rs:12-14)
-    pub fn new(code: &ldpc::codes::LinearCode) -> Self {
-        let c = Code::from_matrix(code.parity_check_matrix());
-        let mut handle = std::ptr::null_mut();
-        check(unsafe { ldpc_flip_create(c.0, &mut handle) });
-        Self { handle, num_bits: code.len() }
+    pub fn new(code: Code) -> Self {
+        let (handle, num_bits) = {
+            let linear: &LinearCode = code.borrow();
+            let c = Code_::from_matrix(linear.parity_check_matrix());
+            let mut handle = std::ptr::null_mut();
+            check(unsafe { ldpc_flip_create(c.0, &mut handle) });
+            (handle, linear.len())
+        };
+        Self { code, handle, num_bits }
     }
 
-    /// `FlipDecoder::decode(&message)` (flip.rs:21-33)
-    pub fn decode(&self, message: &SparseBinVec) -> SparseBinVec {
+    /// `FlipDecoder::decode(&message)` (flip.rs:21-33), for owned vectors and views alike
+    pub fn decode<T>(&self, message: &SparseBinVecBase<T>) -> SparseBinVec
+    where
+        T: std::ops::Deref<Target = [usize]>,
+    {
         let mut out = vec![0usize; self.num_bits];
         let mut n = 0usize;
         let positions = message.as_slice();
@@ -287,6 +361,11 @@ impl GpuFlipDecoder {
         });
         out.truncate(n);
         SparseBinVec::new(self.num_bits, out)
+    }
+
+    /// The code the decoder was built for (flip.rs:45-47 keeps it private; exposed here for callers of `mc_run`).
+    pub fn code(&self) -> &LinearCode {
+        self.code.borrow()
     }
 
     pub fn mc_run(&self, noise: Probability, seed: u64, first_shot: u64, n_shots: usize) -> [u64; LDPC_COUNTERS] {
@@ -308,9 +387,138 @@ impl GpuFlipDecoder {
     }
 }
 
-impl Drop for GpuFlipDecoder {
+/// flip.rs:50-54
+impl<T> fmt::Display for GpuFlipDecoder<T> {
+    fn fmt(&self, f: &mut fmt::Formatter) -> fmt::Result {
+        write!(f, "Flip decoder")
+    }
+}
+
+impl<Code> Drop for GpuFlipDecoder<Code> {
     fn drop(&mut self) {
         unsafe { ldpc_flip_destroy(self.handle) }
+    }
+}
+
+// ---- noise models (ldpc/src/noise) ------------------------------------------------------------
+// The device streams are keyed by (seed, shot) (noise specification).  Behind the crate's
+// `NoiseModel::sample_error_of_length<R: Rng>(&self, length, &mut R)` the caller's generator supplies
+// the seed: one `u64` drawn per sample, shot index 0.  The distributions are the reference's
+// (i.i.d. Bernoulli(p) positions; a uniform non-trivial Pauli on each); the streams are this library's.
+
+/// Drop-in for `ldpc::noise::BinarySymmetricChannel` (binary_symmetric_channel.rs:15-44).
+#[derive(Debug, Clone, Copy, PartialEq)]
+pub struct GpuBinarySymmetricChannel {
+    probability: f64,
+}
+
+impl GpuBinarySymmetricChannel {
+    /// binary_symmetric_channel.rs:22-29
+    pub fn with_probability(probability: Probability) -> Self {
+        Self { probability: probability.value() }
+    }
+}
+
+impl NoiseModel for GpuBinarySymmetricChannel {
+    type Error = SparseBinVec;
+
+    /// binary_symmetric_channel.rs:35-43
+    fn sample_error_of_length<R: Rng>(&self, length: usize, rng: &mut R) -> Self::Error {
+        let mut out = vec![0usize; length];
+        let mut n = 0usize;
+        check(unsafe {
+            ldpc_bsc_sample_error_of_length(self.probability, length, rng.gen::<u64>(), 0, out.as_mut_ptr(), &mut n)
+        });
+        out.truncate(n);
+        SparseBinVec::new(length, out)
+    }
+}
+
+/// binary_symmetric_channel.rs:46-50
+impl fmt::Display for GpuBinarySymmetricChannel {
+    fn fmt(&self, f: &mut fmt::Formatter) -> fmt::Result {
+        write!(f, "BSC({})", self.probability)
+    }
+}
+
+/// Drop-in for `ldpc::noise::DepolarizingNoise` (depolarizing.rs:12-49).
+#[derive(Debug, Clone, Copy, PartialEq)]
+pub struct GpuDepolarizingNoise {
+    probability: f64,
+}
+
+impl GpuDepolarizingNoise {
+    /// depolarizing.rs:20-28
+    pub fn with_probability(probability: Probability) -> Self {
+        Self { probability: probability.value() }
+    }
+}
+
+impl NoiseModel for GpuDepolarizingNoise {
+    type Error = PauliOperator;
+
+    /// depolarizing.rs:34-48
+    fn sample_error_of_length<R: Rng>(&self, length: usize, rng: &mut R) -> Self::Error {
+        let mut positions = vec![0usize; length];
+        let mut codes = vec![0u8; length];
+        let mut n = 0usize;
+        check(unsafe {
+            ldpc_depolarizing_sample_error_of_length(
+                self.probability,
+                length,
+                rng.gen::<u64>(),
+                0,
+                positions.as_mut_ptr(),
+                codes.as_mut_ptr(),
+                &mut n,
+            )
+        });
+        positions.truncate(n);
+        // include/ldpc_hip.h: 1 = X, 2 = Y, 3 = Z
+        let paulis: Vec<Pauli> = codes[..n].iter().map(|c| match c { 1 => X, 2 => Y, _ => Z }).collect();
+        PauliOperator::new(length, positions, paulis)
+    }
+}
+
+/// depolarizing.rs:51-55
+impl fmt::Display for GpuDepolarizingNoise {
+    fn fmt(&self, f: &mut fmt::Formatter) -> fmt::Result {
+        write!(f, "Depolarizing Noise (prob = {})", self.probability)
+    }
+}
+
+/// Drop-in for `ldpc::noise::ErasureChannel` (erasure.rs:14-43).
+#[derive(Debug, Clone, Copy, PartialEq)]
+pub struct GpuErasureChannel {
+    probability: f64,
+}
+
+impl GpuErasureChannel {
+    /// erasure.rs:21-28
+    pub fn with_probability(probability: Probability) -> Self {
+        Self { probability: probability.value() }
+    }
+}
+
+impl NoiseModel for GpuErasureChannel {
+    type Error = SparseBinVec;
+
+    /// erasure.rs:34-42
+    fn sample_error_of_length<R: Rng>(&self, length: usize, rng: &mut R) -> Self::Error {
+        let mut out = vec![0usize; length];
+        let mut n = 0usize;
+        check(unsafe {
+            ldpc_erasure_sample_error_of_length(self.probability, length, rng.gen::<u64>(), 0, out.as_mut_ptr(), &mut n)
+        });
+        out.truncate(n);
+        SparseBinVec::new(length, out)
+    }
+}
+
+/// erasure.rs:45-49
+impl fmt::Display for GpuErasureChannel {
+    fn fmt(&self, f: &mut fmt::Formatter) -> fmt::Result {
+        write!(f, "Erasure({})", self.probability)
     }
 }
 
@@ -328,10 +536,10 @@ unsafe impl Sync for GpuCssMonteCarlo {}
 
 impl GpuCssMonteCarlo {
     pub fn new(code: &ldpc::codes::CssCode, probability: Probability, num_iterations: usize) -> Self {
-        let hx = Code::from_matrix(code.x_stabs_binary());
-        let hz = Code::from_matrix(code.z_stabs_binary());
-        let lx = Code::from_matrix(code.x_logicals_binary());
-        let lz = Code::from_matrix(code.z_logicals_binary());
+        let hx = Code_::from_matrix(code.x_stabs_binary());
+        let hz = Code_::from_matrix(code.z_stabs_binary());
+        let lx = Code_::from_matrix(code.x_logicals_binary());
+        let lz = Code_::from_matrix(code.z_logicals_binary());
         let mut css = std::ptr::null_mut();
         check(unsafe { ldpc_css_create_with_logicals(hx.0, hz.0, lx.0, lz.0, &mut css) });
         let mut handle = std::ptr::null_mut();

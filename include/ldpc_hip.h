@@ -192,12 +192,15 @@ int ldpc_flip_mc_run(ldpc_flip_decoder *dec, double probability, uint64_t seed, 
                      size_t n_shots, uint64_t counters[LDPC_COUNTERS], uint64_t *d_errors_out,
                      uint64_t *d_syndromes_out, uint64_t *d_words_out);
 /* ldpc_flip_mc_run for callers that cannot allocate device memory: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (which has no device).  Same kernels and
- * results as ldpc_flip_mc_run, but every piece of device scratch (counters, parked input words, flip logs) comes
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (which has no device).  Same results as
+ * ldpc_flip_mc_run, bit for bit (the one-wave kernels serve it whatever the size of the run, and the diagnostic
+ * flip limit is ignored), but every piece of device scratch (counters, parked input words, flip logs) comes
  * from a static device array inside the library (64 MiB per GPU, held until the process ends): no hipMalloc, no
- * hipFree, no event, no synchronisation.  The eight counters are copied to d_counters_out (DEVICE memory,
- * [LDPC_COUNTERS] u64) on the library's stream; they and the optional outputs are valid once that stream has been
- * synchronised.  The handle must have served one ordinary call before (its graph and tables are uploaded then).
+ * hipFree, no event, no synchronisation, and only stream operations (one memset, one launch, one copy; a refused call
+ * queues nothing).  The eight counters are copied to d_counters_out (DEVICE memory, [LDPC_COUNTERS] u64) on the
+ * library's stream; they and the optional outputs are valid once that stream has been synchronised.  The handle must
+ * have served one ordinary call before (its graph and tables are uploaded then, and the array's address on that GPU is
+ * looked up then).
  * LDPC_ERR_CAPACITY when a code is too large for the static array (a run is otherwise only slowed: fewer blocks).
  * Calls on one GPU share the array: two that overlap in time (two streams, two threads) race. */
 int ldpc_flip_mc_run_noalloc(ldpc_flip_decoder *dec, double probability, uint64_t seed, uint64_t first_shot,

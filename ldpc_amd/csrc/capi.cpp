@@ -418,6 +418,12 @@ int run_flip(ldpc_flip_decoder *dec, FlipArgs a, uint64_t *counters_out)
     // (the choice of kernel is made once per handle; LDPC_HIP_FLIP_KERNEL = "csr" / "v2" forces the older forms: tests)
     if (dec->path == 0) {
         dec->path = 1;
+        {   // (this GPU's address of the static scratch array is looked up here, once, so that ldpc_flip_mc_run_noalloc
+            // itself makes no call that is not a stream operation)
+            unsigned char *p_ = nullptr;
+            size_t b_ = 0;
+            HIP_TRY(noalloc_scratch(&p_, &b_));
+        }
         std::vector<uint32_t> tab;
         uint32_t kshift = 0, dvp = 0;
         const bool allow_fast = switches().flip_kernel != 1;
@@ -525,6 +531,7 @@ int run_bp(ldpc_bp_decoder *dec, const BpRun &r, uint64_t *counters_out, bool ti
     st = zero_counters(dec->counters);
     if (st) return st;
     const DeviceGraph &g = dec->code.dg;
+    g_bp_executed = 0;   // (an empty call reports no iterations, not the previous call's)
     if (r.n_shots == 0) {
         if (counters_out) return read_counters(dec->counters, counters_out);
         return LDPC_OK;
@@ -1226,12 +1233,13 @@ try {
     a.max_flips = 0xFFFFFFFFu;
     a.counters = (unsigned long long *)base;
     a.flip_log_cap = ((g.m + 15u) & ~15u) + 16u;
-    HIP_TRY(hipMemsetAsync(base, 0, head, g_stream));   // the array keeps the last call's contents: the counters start at zero
+    // (nothing is queued before every capacity check has passed: a refused call leaves the stream as it was)
     if (dec->path == 1) {
         const size_t per_wave = (words_for(g.m) + 2 * words_for(g.n)) * 8;
         if (33 * 8 + per_wave > 160 * 1024)
             return fail(LDPC_ERR_CAPACITY, "ldpc_flip_mc_run_noalloc: per-shot state of " + std::to_string(per_wave) +
                                                " bytes does not fit the LDS of a CU and the static array is not sized for it");
+        HIP_TRY(hipMemsetAsync(base, 0, head, g_stream));   // the array keeps the last call's contents: the counters start at zero
         HIP_TRY(launch_flip(g, a, g_stream));
     } else {
         const size_t word_bytes = std::max<size_t>(words_for(g.n), 1) * 8;
@@ -1248,6 +1256,7 @@ try {
         a.flip_log = (uint32_t *)(base + log_off);
         if (log_off + (size_t)block_cap * 8 * log_bytes > bytes)
             return fail(LDPC_ERR_CAPACITY, "ldpc_flip_mc_run_noalloc: scratch layout exceeds the static array");
+        HIP_TRY(hipMemsetAsync(base, 0, head, g_stream));   // the array keeps the last call's contents: the counters start at zero
         if (dec->path == 3) {
             a.list_cap = flip3_list_cap(a.expected_weight);
             HIP_TRY(launch_flip3(g, dec->nbt3, a, false, g_stream, block_cap));

@@ -890,9 +890,7 @@ __device__ inline uint32_t half_row_or_u32(uint32_t v)
 // in C the compiler spends a second instruction on the `& 31` or on the `& 1`)
 __device__ inline uint32_t bit_of(uint32_t w, uint32_t pos)
 {
-    uint32_t d;
-    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(d) : "v"(w), "v"(pos));
-    return d;
+    return __builtin_amdgcn_ubfe(w, pos, 1u);
 }
 
 // unsatisfied checks of a record >= 2 (bit degree 3: flip.rs:41 `> deg / 2`)
@@ -1046,6 +1044,9 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
 #pragma unroll
             for (uint32_t u = 0; u < P2; u++) r[u] = *(const uint4 *)(nb_base + (((uint32_t)lp[e0 + 4 * u] << 8) | sl16));
         };
+        // (a flippable slot sets its mask bit under an exec mask made by the compare itself -- v_cmpx -- instead of a
+        // branch that, with 64 slots per wave, was always taken; the summary of F is read off F once, after the pass)
+        const uint32_t Fc_addr = lds_addr_of(Fc);
         auto eval = [&](const uint4(&r)[P2]) {
             uint32_t wa[P2], wb[P2], wc[P2];
 #pragma unroll
@@ -1055,11 +1056,18 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
                 wc[u] = *(const uint32_t *)(Sc + (r[u].w >> 16));
             }
 #pragma unroll
-            for (uint32_t u = 0; u < P2; u++)
-                if (bit_of(wa[u], r[u].y) + bit_of(wb[u], r[u].z) + bit_of(wc[u], r[u].w) >= 2) {   // flip.rs:41
-                    atomicOr((uint32_t *)(Fc + (r[u].x >> 16)), 1u << (r[u].x & 31));
-                    summary |= 1u << (r[u].x >> 22);
-                }
+            for (uint32_t u = 0; u < P2; u++) {
+                const uint32_t t = bit_of(wa[u], r[u].y) + bit_of(wb[u], r[u].z) + bit_of(wc[u], r[u].w);   // flip.rs:41: t >= 2
+                const uint32_t fa = Fc_addr + (r[u].x >> 16), fm = 1u << (r[u].x & 31);
+                uint64_t sv;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_cmpx_lt_u32 vcc, 1, %[t]\n\t"
+                             "ds_or_b32 %[fa], %[fm]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(sv)
+                             : [t] "v"(t), [fa] "v"(fa), [fm] "v"(fm)
+                             : "memory", "vcc");
+            }
         };
         uint4 ra[P2], rb[P2];
         if (padded) load(ra, 0);
@@ -1115,6 +1123,12 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
     wave_order();
     if (a.synd_out)
         for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+    // summary of F: bit w = window w (16 mask words) holds a flippable bit
+    {
+        const uint32_t *F32 = (const uint32_t *)F;
+        for (uint32_t d = lane; d < nbt.windows * 16u; d += 64)
+            if (F32[d]) summary |= 1u << (d >> 4);
+    }
     const uint32_t all = (uint32_t)wave_or64(summary);
     if (stamp) {   // diagnostics: noise + list, pass 1, pass 2 + syndrome output
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -1357,6 +1371,143 @@ __device__ inline void flip3_step_v2(const char *nb_base, uint32_t dummy_row, ui
     }
     const uint32_t contrib = (t0 >= 2 ? wb0 : 0u) | (t1 >= 2 ? wb1 : 0u);
     fs2 = keep | half_row_or_u32(contrib);
+}
+
+// The loop of passes of a flip wave, written out by hand (same pass as flip3_step_v2, which is its readable form and
+// stays as the A/B reference): runs passes until some group of the wave has nothing left to flip (fs2 == 0 in its
+// lanes) or `left` passes have run (watchdog: left comes back negative).  What the hand-written form adds to
+// flip3_step_v2: the two DPP reductions of the search interleaved with each other and with the pass's bookkeeping so
+// that no DPP hazard costs a no-op, exec set straight from the compare results (the wave runs with all 64 lanes, which
+// flip4_kernel guarantees), loop control of three scalar instructions, and the last reduction step writing fs2.
+// 95 instructions per pass (66 vector, 12 LDS, 3 vector-memory) against 117 compiled from flip3_step_v2 and 140 from
+// flip3_step; temporaries are fixed registers v80-v124, s[60:73] (clobbered).
+__device__ inline void flip3_passes_asm(const char *nb_base, uint32_t dummy_row, uint32_t wlast, uint32_t Sg_addr, uint32_t Fg_addr,
+                                        uint32_t Fg_lane, const char *log_base, uint32_t log_off, uint32_t gl, uint32_t &fs2,
+                                        uint32_t &nfl, int32_t &left)
+{
+    const uint32_t k1 = gl << 6, k2 = (gl << 6) | 32u, k3 = gl * 32u;
+    asm volatile(
+        "s_mov_b64 s[68:69], exec\n\t"
+        "s_and_b64 s[68:69], s[68:69], %[l0]\n"                    // first lane of every group of eight
+        "1:\n\t"
+        "v_ffbl_b32 v80, %[fs2]\n\t"
+        "v_min_u32 v80, %[wl], v80\n\t"                            // window to scan (fs2 == 0: the last one, empty)
+        "v_lshl_add_u32 v81, v80, 6, %[Fl]\n\t"
+        "ds_read_b64 v[82:83], v81\n\t"
+        "v_lshl_add_u32 v85, %[nfl], 1, %[lo]\n\t"                 // (on the way) where the flip is logged
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_ffbl_b32 v86, v82\n\t"
+        "v_ffbl_b32 v87, v83\n\t"
+        "v_or_b32 v86, v86, %[k1]\n\t"
+        "v_or_b32 v87, v87, %[k2]\n\t"
+        "v_min_u32 v86, v86, v87\n\t"
+        "v_bcnt_u32_b32 v88, v82, 0\n\t"
+        "v_bcnt_u32_b32 v88, v83, v88\n\t"
+        "v_min_u32_dpp v86, v86, v86 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32 v84, -1, %[fs2]\n\t"
+        "v_add_u32_dpp v88, v88, v88 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_min_u32_dpp v86, v86, v86 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_and_b32 v84, v84, %[fs2]\n\t"                           // the summary with the scanned window retired
+        "v_add_u32_dpp v88, v88, v88 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_min_u32_dpp v86, v86, v86 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_lshl_or_b32 v86, v80, 9, v86\n\t"                       // lowest flippable bit (all ones: none)
+        "v_min_u32 v89, %[dr], v86\n\t"                            // ... or the spare row
+        "v_lshl_or_b32 v90, v89, 8, %[k3]\n\t"
+        "global_load_dwordx4 v[92:95], v90, %[nb]\n\t"
+        "global_load_dwordx4 v[96:99], v90, %[nb] offset:16\n\t"
+        "v_add_u32_dpp v88, v88, v88 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        // while the row is on its way: retire the window if the bit about to be flipped was its only one; count the flip
+        // (gfx950: a lane mask written by a vector compare may be read by a vector instruction two instructions later at
+        // the earliest -- the compiler pads with s_nop; here the order provides the distance, and this stretch is in the
+        // shadow of the row load anyway)
+        "v_cmp_gt_u32_e64 s[60:61], 2, v88\n\t"
+        "v_cmp_gt_u32_e64 s[62:63], %[dr], v86\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 v84, %[fs2], v84, s[60:61]\n\t"
+        "v_cndmask_b32_e64 v91, 0, 1, s[62:63]\n\t"
+        "v_add_u32 %[nfl], %[nfl], v91\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        // slot 0 of the group's first lane is the bit itself: syndrome ^= H e_b (flip.rs:28-29), the flip is logged
+        "v_add_u32_sdwa v100, v93, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32 v106, v93, v91\n\t"
+        "v_add_u32_sdwa v101, v94, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32 v107, v94, v91\n\t"
+        "v_add_u32_sdwa v102, v95, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32 v108, v95, v91\n\t"
+        "s_mov_b64 exec, s[68:69]\n\t"
+        "ds_xor_b32 v100, v106\n\t"
+        "ds_xor_b32 v101, v107\n\t"
+        "ds_xor_b32 v102, v108\n\t"
+        "global_store_short v85, v89, %[lb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_waitcnt vmcnt(1)\n\t"                                   // (the second half of the row; the store stays out)
+        "v_add_u32_sdwa v103, v97, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_add_u32_sdwa v104, v98, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_add_u32_sdwa v105, v99, %[Sg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        // both slots of the lane against the new syndrome: six words in one LDS round trip
+        "ds_read_b32 v109, v100\n\t"
+        "ds_read_b32 v110, v101\n\t"
+        "ds_read_b32 v111, v102\n\t"
+        "ds_read_b32 v112, v103\n\t"
+        "ds_read_b32 v113, v104\n\t"
+        "ds_read_b32 v114, v105\n\t"
+        // on the way: where and what a slot would write, its window, its flag
+        "v_add_u32_sdwa v115, v92, %[Fg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_add_u32_sdwa v116, v96, %[Fg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32 v117, v92, v91\n\t"
+        "v_lshlrev_b32 v118, v96, v91\n\t"
+        "v_lshrrev_b32 v119, 22, v92\n\t"
+        "v_lshrrev_b32 v120, 22, v96\n\t"
+        "v_and_b32 v121, 0x100, v92\n\t"
+        "v_and_b32 v122, 0x100, v96\n\t"
+        "v_lshlrev_b32 v119, v119, 1\n\t"
+        "v_lshlrev_b32 v120, v120, 1\n\t"
+        "v_cmp_ne_u32_e64 s[60:61], 0, v121\n\t"
+        "v_cmp_ne_u32_e64 s[62:63], 0, v122\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // One of a neighbour's checks changed by this flip, so its mask bit changes only if the other two hold exactly
+        // one unsatisfied check; the flag covers the records for which that does not hold.  flip.rs:41 for three
+        // checks: flippable iff two or more are unsatisfied.
+        "v_bfe_u32 v109, v109, v93, 1\n\t"
+        "v_bfe_u32 v110, v110, v94, 1\n\t"
+        "v_bfe_u32 v111, v111, v95, 1\n\t"
+        "v_bfe_u32 v112, v112, v97, 1\n\t"
+        "v_bfe_u32 v113, v113, v98, 1\n\t"
+        "v_bfe_u32 v114, v114, v99, 1\n\t"
+        "v_add3_u32 v121, v109, v110, v111\n\t"
+        "v_add3_u32 v122, v112, v113, v114\n\t"
+        "v_cmp_lt_u32_e64 s[70:71], 1, v121\n\t"
+        "v_cmp_lt_u32_e64 s[72:73], 1, v122\n\t"
+        "v_cmp_ne_u32_e64 s[64:65], v109, v110\n\t"
+        "v_cmp_ne_u32_e64 s[66:67], v112, v113\n\t"
+        "v_cndmask_b32_e64 v123, 0, v117, s[70:71]\n\t"
+        "v_cndmask_b32_e64 v119, 0, v119, s[70:71]\n\t"
+        "v_cndmask_b32_e64 v124, 0, v118, s[72:73]\n\t"
+        "v_cndmask_b32_e64 v120, 0, v120, s[72:73]\n\t"
+        "s_or_b64 exec, s[64:65], s[60:61]\n\t"
+        "ds_mskor_b32 v115, v117, v123\n\t"
+        "s_or_b64 exec, s[66:67], s[62:63]\n\t"
+        "ds_mskor_b32 v116, v118, v124\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_or3_b32 v119, v119, v120, v84\n\t"                      // windows that hold a flippable bit now, and the ones kept
+        "s_sub_u32 %[left], %[left], 1\n\t"
+        "s_nop 0\n\t"
+        "v_or_b32_dpp v119, v119, v119 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_or_b32_dpp v119, v119, v119 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_or_b32_dpp %[fs2], v119, v119 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cmp_eq_u32 vcc, 0, %[fs2]\n\t"
+        "s_cbranch_vccnz 2f\n\t"                                   // some group is out of flips
+        "s_cbranch_scc0 1b\n"
+        "2:"
+        : [fs2] "+v"(fs2), [nfl] "+v"(nfl), [left] "+s"(left)
+        : [wl] "s"(wlast), [dr] "s"(dummy_row), [Fl] "v"(Fg_lane), [Fg] "v"(Fg_addr), [Sg] "v"(Sg_addr), [lo] "v"(log_off), [k1] "v"(k1),
+          [k2] "v"(k2), [k3] "v"(k3), [nb] "s"(nb_base), [lb] "s"(log_base), [l0] "s"(0x0101010101010101ull)
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "v80", "v81", "v82", "v83", "v84",
+          "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102",
+          "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118",
+          "v119", "v120", "v121", "v122", "v123", "v124");
 }
 
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
@@ -1614,7 +1765,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     }
     // ===================================================================== flip wave
     if (a.max_flips == 1) __builtin_amdgcn_s_setprio(3);   // (experiment) the serial chains win the issue arbitration
-    constexpr bool V2 = SV == 3;
+    constexpr bool V2 = SV == 3 || SV == 4;
     uint32_t slot = NONE, fs2 = 0, nfl = 0, idle = 0, steps = 0;
     char *Sg = (char *)state, *Fg = Sg + (size_t)Sw * 8;
     // (V2: LDS byte addresses; a group without a shot scans the zeroed window of the control block)
@@ -1628,6 +1779,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     unsigned long long p_iter = 0, p_live = 0, p_start = 0, p_stamp[4] = {0, 0, 0, 0};
     if (PROF) p_start = __builtin_amdgcn_s_memtime();
     for (;;) {
+        const unsigned long long p_live0 = p_live;
         if (PROF) {
             p_iter++;
             p_live += (unsigned long long)__builtin_popcountll(__ballot(fs2 != 0 && gl == 0));
@@ -1636,6 +1788,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
             // ---- some group has nothing to flip: hand finished shots back, take prepared ones
             const bool finished = fs2 == 0 && slot != NONE;
             if (__ballot(finished)) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (log entries stored from inline asm: the compiler does not count them)
                 wave_sync();   // this wave's log entries are in memory
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (finished && gl == 0) {
@@ -1711,10 +1864,20 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
         if (V2) {
             // passes until some group runs out of flips (a shot ends within step_cap passes, so a wave that runs more
             // than that without a shot ending is stuck -- cannot happen; never spin on a bug)
-            uint32_t left = step_cap;
-            do flip3_step_v2((const char *)nbt.rec, g.n, wlast, Sg_addr, Fg_addr, Fg_addr + gl * 8u, log_base, log_off, gl, fs2, nfl);
-            while (!__ballot(fs2 == 0) && --left);
-            if (!left) {
+            int32_t left = (int32_t)step_cap;
+            if (SV == 4) {
+                flip3_passes_asm((const char *)nbt.rec, g.n, wlast, Sg_addr, Fg_addr, Fg_addr + gl * 8u, log_base, log_off, gl, fs2, nfl, left);
+            } else {
+                do flip3_step_v2((const char *)nbt.rec, g.n, wlast, Sg_addr, Fg_addr, Fg_addr + gl * 8u, log_base, log_off, gl, fs2, nfl);
+                while (!__ballot(fs2 == 0) && --left > 0);
+                if (left <= 0) left = -1;
+            }
+            if (PROF) {   // (the loop's top has counted one pass and its live groups)
+                const uint32_t more = step_cap - (uint32_t)left - 1u;
+                p_live += (unsigned long long)more * (p_live - p_live0);
+                p_iter += more;
+            }
+            if (left < 0) {
                 if (lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
@@ -3569,16 +3732,21 @@ uint32_t flip4_scratch_pieces() { return device_cu_count() * F4_LOGS; }
 typedef void (*flip4_fn)(DeviceGraph, Nb3Table, FlipArgs, uint32_t);
 static flip4_fn flip4_kernel_for(uint32_t nf, bool prof)
 {
+    // (SV = 4: the hand-written loop of passes; 3: its compiled form flip3_step_v2; 0: round 2's flip3_step.  Codes
+    // 100 * SV' + flip waves are A/B aids: LDPC_HIP_FLIP_NF.)
     switch (nf) {
-    case 4: return flip4_kernel<4>;
-    case 6: return flip4_kernel<6>;
-    case 7: return flip4_kernel<7>;
-    case 8: return prof ? flip4_kernel<8, true> : flip4_kernel<8>;
-    case 9: return prof ? flip4_kernel<9, true> : flip4_kernel<9>;
-    case 10: return flip4_kernel<10>;
-    case 109: return flip4_kernel<9, false, 8, 7, 1>;
-    case 209: return flip4_kernel<9, false, 8, 7, 2>;
+    case 4: return flip4_kernel<4, false, 8, 12, 4>;
+    case 6: return flip4_kernel<6, false, 8, 10, 4>;
+    case 7: return prof ? flip4_kernel<7, true, 8, 9, 4> : flip4_kernel<7, false, 8, 9, 4>;
+    case 8: return prof ? flip4_kernel<8, true, 8, 8, 4> : flip4_kernel<8, false, 8, 8, 4>;
+    case 9: return prof ? flip4_kernel<9, true, 8, 7, 4> : flip4_kernel<9, false, 8, 7, 4>;
+    case 10: return flip4_kernel<10, false, 8, 6, 4>;
+    case 109: return prof ? flip4_kernel<9, true> : flip4_kernel<9>;
+    case 108: return flip4_kernel<8>;
+    case 119: return flip4_kernel<9, false, 8, 7, 1>;   // issue-slot probes on round 2's pass: ten more scalar / vector instructions
+    case 129: return flip4_kernel<9, false, 8, 7, 2>;
     case 309: return flip4_kernel<9, false, 8, 7, 3>;
+    case 308: return flip4_kernel<8, false, 8, 8, 3>;
     default: return nullptr;
     }
 }
@@ -3589,10 +3757,13 @@ hipError_t launch_flip4(const DeviceGraph &g, const Nb3Table &nb, const FlipArgs
     if (a.list_cap % 64 || a.list_cap < 64) return hipErrorInvalidValue;
     // flip waves of the 16: measured at C2 8 -> 7.2e7, 9 -> 7.6e7 shots/s, 10 -> the service waves do not keep up
     // (LDPC_HIP_FLIP_NF: A/B aid); fewer when the LDS holds fewer slots than their groups plus one per service wave
-    uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 9u;
+    uint32_t nf = switches().flip_nf >= 4 && switches().flip_nf <= 10 ? (uint32_t)switches().flip_nf : 8u;
     while (nf > 4 && (!flip4_kernel_for(nf, false) || flip4_slots(nb, a.list_cap, nf) < nf * 8 + (16 - nf))) nf--;
     flip4_fn k = flip4_kernel_for(nf, switches().flip_prof);
-    if (nf == 9 && switches().flip_nf > 100 && flip4_kernel_for(switches().flip_nf, false)) k = flip4_kernel_for(switches().flip_nf, false);
+    if (switches().flip_nf > 100 && flip4_kernel_for(switches().flip_nf, false)) {   // A/B forms: 100 * variant + flip waves
+        nf = (uint32_t)switches().flip_nf % 100;
+        k = flip4_kernel_for(switches().flip_nf, switches().flip_prof);
+    }
     const uint32_t n_slots = flip4_slots(nb, a.list_cap, nf);
     if (!k || n_slots < nf * 8 + 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)flip4_hdr_words(a.list_cap, 16 - nf) + (size_t)n_slots * (nb.sw + nb.windows * 8)) * 8;

@@ -49,12 +49,10 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
         d2.mc_run(p, SEED, 0, 8)
         _both(d2, nn, mm, p, 10, shots)
         _both(d2, nn, mm, p, 0, shots // 3)
-    # a code whose per-block scratch cannot fit is refused with a clear error
+    # a code on the generic kernel (n = 400,000: a shot's state fills most of a CU's LDS, no scratch pieces at all):
+    # the entry point serves it, bit for bit like the allocating call.  (The refusal of a code beyond the array,
+    # n = 10^6, is tested in tests/test_gpu_flip.py.)
     big = LinearCode.random_regular_code(400000, 200000, 3, 6, seed=1)
     dbig = FlipDecoder(big)
     dbig.mc_run(0.001, SEED, 0, 4)
-    try:
-        dbig.mc_run_noalloc(0.001, SEED, 0, 4, torch.zeros(8, dtype=torch.int64, device="cuda"))
-        torch.cuda.synchronize()
-    except ldpc_amd.LdpcError as e:
-        assert e.status == ldpc_amd.ERR_CAPACITY
+    _both(dbig, 400000, 200000, 0.001, 0, 4)
