@@ -1007,10 +1007,29 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
             }
         }
     }
-    wave_sync();   // O is read back from memory below (overflow path) and by the output stage
+    // (LDS only: the list and its counter.  The parked word is read back by the overflow path below, which waits for
+    // it, and by the output stage, behind the release at the end of the set-up.  A service wave runs on memory round
+    // trips and on the LDS, not on instruction issue -- a quarter fewer instructions in pass 2 bought nothing, one
+    // round trip less in the output stage 2.8 % of the whole kernel -- so nothing here waits for a store that nobody
+    // is about to read.)
+    wave_order();
     if (stamp) ts1 = __builtin_amdgcn_s_memtime();
     const uint32_t total = __builtin_amdgcn_readfirstlane(*cnt_lds);
+    bool synd_written = false;
     if (total <= LIST_CAP) {
+        // (pass 2's list padding is written here, ahead of pass 1, which only reads entries below `total`)
+        constexpr uint32_t P2 = 8;
+        const uint32_t padded = (total + 4 * P2 - 1) & ~(4 * P2 - 1);   // <= LIST_CAP (a multiple of 64)
+        if (total + lane < padded) list[total + lane] = (uint16_t)dummy_row;
+        wave_order();
+        const char *nb_base = (const char *)nb;
+        const uint32_t sl16 = (lane & 15) << 4;
+        const uint16_t *lp = list + (lane >> 4);
+        auto load = [&](uint4(&r)[P2], uint32_t e0) {
+#pragma unroll
+            for (uint32_t u = 0; u < P2; u++) r[u] = *(const uint4 *)(nb_base + (((uint32_t)lp[e0 + 4 * u] << 8) | sl16));
+        };
+        uint4 ra[P2], rb[P2];
         // pass 1, syndrome: toggle the three checks of every error bit (slot 0 of its row)
         for (uint32_t t0i = lane; t0i < total; t0i += 64 * 4) {
             uint4 r[4];
@@ -1027,23 +1046,16 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         }
         wave_order();
         if (stamp) ts2 = __builtin_amdgcn_s_memtime();
+        // (the syndrome is final: its record goes out now, and is long in memory when the set-up ends)
+        if (a.synd_out)
+            for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
+        synd_written = true;
         // pass 2, flippable mask: only bits next to an error bit can see an unsatisfied check; a padding
         // slot reads the spare check and is never flippable.  Lane = slot (lane & 15) of the errors lane / 16 + 4 u:
         // the list is padded with the spare row to a multiple of 32 entries, so no lane needs a bounds test, the list
         // reads differ by constant offsets and a row address is one shift-or on a 32-bit offset.
-        constexpr uint32_t P2 = 8;
-        const uint32_t padded = (total + 4 * P2 - 1) & ~(4 * P2 - 1);   // <= LIST_CAP (a multiple of 64)
-        if (total + lane < padded) list[total + lane] = (uint16_t)dummy_row;
-        wave_order();
-        const char *nb_base = (const char *)nb;
-        const uint32_t sl16 = (lane & 15) << 4;
-        const uint16_t *lp = list + (lane >> 4);
         // (two sets of records: the rows of the next 32 errors are on their way while this set is evaluated; a set's
         // 24 syndrome words are read together, then the slots decide)
-        auto load = [&](uint4(&r)[P2], uint32_t e0) {
-#pragma unroll
-            for (uint32_t u = 0; u < P2; u++) r[u] = *(const uint4 *)(nb_base + (((uint32_t)lp[e0 + 4 * u] << 8) | sl16));
-        };
         // (a flippable slot sets its mask bit under an exec mask made by the compare itself -- v_cmpx -- instead of a
         // branch that, with 64 slots per wave, was always taken; the summary of F is read off F once, after the pass)
         const uint32_t Fc_addr = lds_addr_of(Fc);
@@ -1069,7 +1081,7 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
                              : "memory", "vcc");
             }
         };
-        uint4 ra[P2], rb[P2];
+        // (asking for these rows before pass 1 works its own measured slower: 40.1 -> 40.6 ms per 2^22 shots)
         if (padded) load(ra, 0);
         for (uint32_t e0 = 0; e0 < padded; e0 += 8 * P2) {
             const bool second = e0 + 4 * P2 < padded;
@@ -1082,6 +1094,7 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         }
     } else {
         // more errors than the list holds: the same two passes over pieces of LIST_CAP / 64 words
+        wave_sync();   // (the parked word is read back from memory)
         const uint32_t pw = LIST_CAP / 64;
         for (int pass = 0; pass < 2; pass++) {
             for (uint32_t wb = 0; wb < Wn; wb += pw) {
@@ -1121,7 +1134,7 @@ __device__ inline uint32_t flip3_setup_shot(const DeviceGraph &g, const Nb3Table
         }
     }
     wave_order();
-    if (a.synd_out)
+    if (a.synd_out && !synd_written)
         for (uint32_t w = lane; w < Wm; w += 64) a.synd_out[i * Wm + w] = S[w];
     // summary of F: bit w = window w (16 mask words) holds a flippable bit
     {
@@ -1146,17 +1159,32 @@ __device__ inline uint32_t flip3_output_shot(const DeviceGraph &g, const Nb3Tabl
     const uint32_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
     uint64_t *Oj = S + nbt.sw;
     uint32_t *O32 = (uint32_t *)Oj;
-    // device-scope loads: both were written through other lanes / waves of this CU
+    // device-scope loads: both were written through other lanes / waves of this CU.  The log is read two entries a load
+    // (it is 32-byte aligned), and its first 512 entries are asked for together with the parked word: one memory round
+    // trip for both.
+    const uint32_t *lj32 = (const uint32_t *)lj;
+    const uint32_t npair = (nf + 1) >> 1;
+    uint32_t bb[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+        bb[u] = lane + 64 * u < npair ? __hip_atomic_load(&lj32[lane + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     for (uint32_t w = lane; w < Wn; w += 64) Oj[w] = __hip_atomic_load(&E[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wave_order();
-    for (uint32_t t0i = lane; t0i < nf; t0i += 64 * 4) {
-        uint32_t bb[4];
+    for (uint32_t t0i = lane;;) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t pi = t0i + 64 * u;
+            if (pi < npair) {
+                const uint32_t b0 = bb[u] & 0xFFFFu, b1 = bb[u] >> 16;
+                atomicXor(&O32[b0 >> 5], 1u << (b0 & 31));                                     // flip.rs:30
+                if (2 * pi + 1 < nf) atomicXor(&O32[b1 >> 5], 1u << (b1 & 31));
+            }
+        }
+        t0i += 64 * 4;
+        if (t0i - lane >= npair) break;
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++)
-            bb[u] = t0i + 64 * u < nf ? (uint32_t)__hip_atomic_load(&lj[t0i + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NONE;
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
-            if (bb[u] != NONE) atomicXor(&O32[bb[u] >> 5], 1u << (bb[u] & 31));                // flip.rs:30
+            bb[u] = t0i + 64 * u < npair ? __hip_atomic_load(&lj32[t0i + 64 * u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     wave_order();
     uint64_t anyo = 0, anys = 0;
@@ -1451,6 +1479,10 @@ __device__ inline void flip3_passes_asm(const char *nb_base, uint32_t dummy_row,
         "ds_read_b32 v112, v103\n\t"
         "ds_read_b32 v113, v104\n\t"
         "ds_read_b32 v114, v105\n\t"
+#ifdef XP_LDS_PROBE   // (what two more random 64-lane LDS reads cost a pass: profiles/README.md round 3)
+        "ds_read_b32 v125, v103\n\t"
+        "ds_read_b32 v126, v104\n\t"
+#endif
         // on the way: where and what a slot would write, its window, its flag
         "v_add_u32_sdwa v115, v92, %[Fg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
         "v_add_u32_sdwa v116, v96, %[Fg] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
@@ -1507,7 +1539,7 @@ __device__ inline void flip3_passes_asm(const char *nb_base, uint32_t dummy_row,
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "v80", "v81", "v82", "v83", "v84",
           "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102",
           "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118",
-          "v119", "v120", "v121", "v122", "v123", "v124");
+          "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
 }
 
 template <bool PROF> __global__ __launch_bounds__(64) void flip3_kernel(DeviceGraph g, Nb3Table nbt, FlipArgs a)
@@ -1725,7 +1757,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
                 const uint32_t nfj = __builtin_amdgcn_readfirstlane(ctl->nfl[slot]), nf = nfj < a.flip_log_cap ? nfj : a.flip_log_cap;
                 const uint32_t r = flip3_output_shot(g, nbt, a, S, err_words(slot, rel), log_of(slot), nf, lo + rel, lane);
                 c_shots++; c_fail += r & 1; c_det += (r >> 1) & 1; c_undet += r == 1; c_flips += nf;
-                wave_sync();
+                wave_order();   // (the slot's LDS is read; its records in memory are nobody's to read inside the kernel)
                 if (lane == 0) __hip_atomic_fetch_add(&ctl->n_output, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (PROF) p_svc[3] += __builtin_amdgcn_s_memtime() - to0;
             }
