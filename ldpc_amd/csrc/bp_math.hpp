@@ -120,6 +120,16 @@ template <bool SK = false> __device__ inline double bp_tanh_half(double x)
 // bp_tanh_half of the first cnt of N values, statement by statement across the batch: every value goes through the
 // operations of bp_tanh_half in their order (the same results, bit for bit), and a constant of the polynomial is
 // built once per batch instead of once per value.
+// Round 2 tried this batch for bits of ANY degree up to eight in bp_lds_kernel's general bit update and dropped it after
+// a wrong result in one irregular code (a build with 73 spilled registers).  Round 3 rebuilt that variant
+// (-DBPL_TANH_BATCH_ANY=1: count = the lane's own degree; =2: the wave's largest) and could not make it fail: on the
+// seven irregular codes of the suite (bit degrees 0 to 14, 35 cases each, scripts/tanh_batch_repro.py) it is
+// bit-identical to the one-by-one form and to bp_kernel, and the routine itself equals bp_tanh_half bit for bit for every
+// count, uniform or per lane, with either kind of constant (tests/test_gpu_bp_math.py::test_tanh_batch_equals_the_single_form;
+// elements from the count on are never read or written).  So the routine has no predicate or indexing fault, and the
+// variant as rebuilt here (values beyond a bit's degree zeroed before the batch, results stored under `k < dv`) is
+// correct; the round-2 build that failed is not in the tree and its fault cannot be examined further.  The variant
+// stays out for its cost alone: seven arrays of eight doubles per lane spill.
 template <int N, bool SK> __device__ inline void bp_tanh_half_n(const double (&x)[N], double (&out)[N], int cnt)
 {
     double a[N], kn[N], rh[N], rl[N], r[N], rc[N], q[N];

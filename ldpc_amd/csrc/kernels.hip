@@ -64,6 +64,16 @@ __device__ inline uint64_t wave_sum64(uint64_t x)
     return x;
 }
 
+__device__ inline uint32_t wave_max_u32(uint32_t x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(x, off, 64);
+        x = o > x ? o : x;
+    }
+    return x;
+}
+
 __device__ inline uint64_t readlane64(uint64_t x, uint32_t l)
 {
     uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, l);
@@ -175,6 +185,24 @@ __global__ __launch_bounds__(256) void bp_math_probe_kernel(int kind, uint64_t n
         case 3: v = log1p(in[t]); break;
         case 4: v = bp_div_core(in[t], in[n + t]); break;
         case 5: v = bp_ref_atanh(in[t]); break;
+        case 7: case 8: case 9: case 10: {
+            // bp_tanh_half_n, the batch form of bp_tanh_half, on the eight values in[8 (t / 8)..]: the result of element t % 8,
+            // or NaN's stand-in -7.0 where the count leaves it out.  7 / 8: the scalar-constant form with a count that is
+            // the same for the whole wave (blockIdx-dependent) / differs from lane to lane; 9 / 10: the plain form likewise.
+            double x8[8], y8[8];
+            const uint64_t base = t & ~(uint64_t)7;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                x8[j] = base + j < n ? in[base + j] : 0.0;
+                y8[j] = -7.0;
+            }
+            const int cnt = (kind & 1) ? (int)((blockIdx.x + (t >> 8)) % 9) : (int)((t >> 3) % 9);
+            if (kind <= 8) bp_tanh_half_n<8, true>(x8, y8, cnt);
+            else bp_tanh_half_n<8, false>(x8, y8, cnt);
+            v = y8[t & 7];
+            out[n + t] = (double)cnt;   // (the second half of out: the count that was used)
+            break;
+        }
         default: v = bp_div_prod(in[t], in[n + t]); break;
         }
         out[t] = v;
@@ -2900,9 +2928,13 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                             if (DV > 0 || __ballot(dv == RD) != 0) bp_tanh_half_n<(int)RD, BPL_SK>(v, y, (int)RD);
                             else bp_tanh_half_n<(int)RD, BPL_SK>(v, y, (int)RD - 1);
                         } else {
+#ifdef BPL_TANH_BATCH_ANY   // (diagnostic build: round 2's dropped variant, the batch for bits of any degree up to REG_DEG)
+                            bp_tanh_half_n<(int)RD, BPL_SK>(v, y, BPL_TANH_BATCH_ANY == 1 ? (int)dv : (int)__builtin_amdgcn_readfirstlane(wave_max_u32(dv)));
+#else
 #pragma unroll
                             for (uint32_t k = 0; k < RD; k++)
                                 if (DV > 0 || k < dv) y[k] = bp_tanh_half<BPL_SK>(v[k]);
+#endif
                         }
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
