@@ -1740,6 +1740,9 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     if (wave >= NF) {
         // ================================================================= service wave
         const uint32_t h = wave - NF;
+#ifdef XP_SVC_PRIO   // (experiment: the service waves, which the flip waves wait for, win the issue arbitration)
+        __builtin_amdgcn_s_setprio(XP_SVC_PRIO);
+#endif
         uint16_t *list = lists + (size_t)h * LIST_CAP;
         uint32_t *cnt_lds = &ctl->cnt[h];
         uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;

@@ -44,6 +44,22 @@ flip = {
     "counters_per_launch": {n: v / launches for n, v in k["counters"].items()},
 }
 json.dump(flip, open(os.path.join(dst, "%s_flip_pmc.json" % tag), "w"), indent=1)
+# pipe utilisation of the same kernel (the sq / wait passes of the same command), as bench.py's flip_binder() reads it
+c = flip["counters_per_launch"]
+cycles_xcd = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+pipes = {
+    "command": flip["command"], "kernel": flip["kernel"], "launches_averaged": launches, "shots_per_launch": shots,
+    "cycles_per_xcd": cycles_xcd,
+    "valu_instructions_per_shot": c.get("SQ_INSTS_VALU", 0) / shots, "salu_instructions_per_shot": c.get("SQ_INSTS_SALU", 0) / shots,
+    "lds_instructions_per_shot": c.get("SQ_INSTS_LDS", 0) / shots,
+    # one vector instruction counted as four cycles of its SIMD (SQ_ACTIVE_INST_VALU counts quad-cycles); scripts/ubench_ops.hip
+    # measures 1.9 - 3.5 cycles per wave-instruction with four waves per SIMD, so this figure overstates how full the pipes are
+    "valu_pipe_busy": c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(cycles_xcd * 1024, 1),
+    "lds_array_busy": c.get("SQ_LDS_IDX_ACTIVE", 0) / max(cycles_xcd * 256, 1),
+    "lds_bank_conflict_share": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+    "lds_array_cycles_per_shot": c.get("SQ_LDS_IDX_ACTIVE", 0) / shots,
+}
+json.dump(pipes, open(os.path.join(dst, "%s_flip_pipes.json" % tag), "w"), indent=1)
 out["flip_ms"] = flip["kernel_stats_avg_ms"]
 out["flip_traffic_per_shot"] = flip["traffic_bytes_per_shot"]
 
