@@ -1740,9 +1740,8 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     if (wave >= NF) {
         // ================================================================= service wave
         const uint32_t h = wave - NF;
-#ifdef XP_SVC_PRIO   // (experiment: the service waves, which the flip waves wait for, win the issue arbitration)
-        __builtin_amdgcn_s_setprio(XP_SVC_PRIO);
-#endif
+        // (A raised priority for these waves, s_setprio 2, measured 18 % slower in round 3: they wait on memory, and the
+        // flip waves they then push aside are the ones whose finished shots they need.  profiles/README.md.)
         uint16_t *list = lists + (size_t)h * LIST_CAP;
         uint32_t *cnt_lds = &ctl->cnt[h];
         uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
