@@ -203,8 +203,10 @@ def bp_roofline(alg_bytes, ms, pmc, kernel="", reference_bytes=None, shots=None)
 def flip_binder():
     """What binds the headline kernel (for the LDS-resident flip kernel the HBM fraction is small by
     construction): the instruction stream of a pass, with the counters of the tracked pass replayed and their source named."""
-    text = ("not HBM: a flip wave issues the ~95 instructions of a pass (8 flips) at one per ~4.5 cycles and waits for one L2 row "
-            "and two LDS round trips; 72 of the 81 shots a CU's LDS holds are in such a pass at any time")
+    text = ("not HBM: per CU eight flip waves run the serial chains of 64 shots (a pass = ~95 instructions for 8 flips, one L2 "
+            "row and three LDS round trips, ~1100 cycles) and eight service waves prepare / write out shots through the "
+            "other LDS slots; the service waves are the binder (96 % busy: profiles/r03_flip_waves.txt), with the LDS "
+            "array 65 % and the VALU pipes 81 % busy")
     d = _profile(FLIP_PIPES)
     try:
         return {"what": text, "valu_pipe_busy": d["valu_pipe_busy"], "valu_instructions_per_shot": d["valu_instructions_per_shot"],
