@@ -85,6 +85,9 @@ def bp(sub, name, kernel, edges, label):
         "hbm_read_bytes": k.get("hbm_read_bytes"), "hbm_write_bytes": k.get("hbm_write_bytes"), "traffic_bytes": k.get("hbm_traffic_bytes"),
         "traffic_over_algorithmic": k.get("hbm_traffic_bytes", 0) / alg,
         "valu_pipe_busy": k["counters"].get("SQ_ACTIVE_INST_VALU", 0) * 4 / (k["counters"].get("GRBM_GUI_ACTIVE", 1) / 8 * 1024),
+        # shader clock while the kernel ran: cycles of the counter pass / duration of the trace pass (same command)
+        "shader_clock_ghz": k["counters"].get("GRBM_GUI_ACTIVE", 0) / 8 / max(k["time"]["total_ms"] * 1e6, 1),
+        "valu_instructions_per_s": k["counters"].get("SQ_INSTS_VALU", 0) / max(k["time"]["total_ms"] * 1e-3, 1e-9),
         "counters": k["counters"],
     }
     json.dump(d, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, name)), "w"), indent=1)
