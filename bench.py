@@ -205,8 +205,9 @@ def flip_binder():
     construction): the instruction stream of a pass, with the counters of the tracked pass replayed and their source named."""
     text = ("not HBM: per CU eight flip waves run the serial chains of 64 shots (a pass = ~95 instructions for 8 flips, one L2 "
             "row and three LDS round trips, ~1100 cycles) and eight service waves prepare / write out shots through the "
-            "other LDS slots; the service waves are the binder (96 % busy: profiles/r03_flip_waves.txt), with the LDS "
-            "array 65 % and the VALU pipes 81 % busy")
+            "other LDS slots; both kinds of wave are saturated (7.97 of 8 flip groups live in every pass, service waves "
+            "96 % busy: profiles/r03_flip_waves.txt), 16 waves and 80 slots are all a CU's workgroup and LDS allow, with "
+            "the LDS array 65 % and the VALU pipes 81 % busy")
     d = _profile(FLIP_PIPES)
     try:
         return {"what": text, "valu_pipe_busy": d["valu_pipe_busy"], "valu_instructions_per_shot": d["valu_instructions_per_shot"],

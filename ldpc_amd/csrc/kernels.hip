@@ -1841,11 +1841,6 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
     unsigned long long p_iter = 0, p_live = 0, p_start = 0, p_stamp[4] = {0, 0, 0, 0};
     if (PROF) p_start = __builtin_amdgcn_s_memtime();
     for (;;) {
-        const unsigned long long p_live0 = p_live;
-        if (PROF) {
-            p_iter++;
-            p_live += (unsigned long long)__builtin_popcountll(__ballot(fs2 != 0 && gl == 0));
-        }
         if (__ballot(fs2 == 0)) {
             // ---- some group has nothing to flip: hand finished shots back, take prepared ones
             const bool finished = fs2 == 0 && slot != NONE;
@@ -1923,6 +1918,14 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
             }
             idle = 0;
         }
+        // (diagnostics: groups with a shot to work on, counted after the hand-off above -- a group whose shot has just
+        // ended is live again if a prepared one was there for it)
+        unsigned long long p_now = 0;
+        if (PROF) {
+            p_now = (unsigned long long)__builtin_popcountll(__ballot(fs2 != 0 && slot != NONE && gl == 0));
+            p_iter++;
+            p_live += p_now;
+        }
         if (V2) {
             // passes until some group runs out of flips (a shot ends within step_cap passes, so a wave that runs more
             // than that without a shot ending is stuck -- cannot happen; never spin on a bug)
@@ -1936,7 +1939,7 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
             }
             if (PROF) {   // (the loop's top has counted one pass and its live groups)
                 const uint32_t more = step_cap - (uint32_t)left - 1u;
-                p_live += (unsigned long long)more * (p_live - p_live0);
+                p_live += (unsigned long long)more * p_now;
                 p_iter += more;
             }
             if (left < 0) {
