@@ -2725,6 +2725,24 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
     // (the index of the next shot is asked for at the start of the current one's first bit update and put in the
     // other queue slot at its end: the queue's round trip is off the path and the answer is not kept across a check row)
     if (tid == 0) sh_queue[0] = atomicAdd(a.queue, 1ull);
+    // HYB: the checks and the bits of a phase are handed to the waves 64 at a time from a counter in LDS instead of by
+    // thread index.  A check or bit whose messages live in the L2 piece costs about twice one whose messages are in
+    // LDS, the fixed split gave some waves one such check in five and others two, and every phase ends at a barrier:
+    // wave 0 spent a sixth of a shot waiting there (profiles/r02_bp_lds_phases.txt).  One counter serves all phases:
+    // it only grows, a phase's chunks are its values from `wbase` on, and a phase takes exactly chunks + waves of them
+    // (every wave's last grab fails), which every wave adds to its own copy of wbase -- no reset, no extra barrier.
+    // Each check and bit is computed by the same code whichever wave takes it: results do not depend on the hand-out.
+    uint32_t *sh_work = q + 67;   // (the spare word after the gap table's 65, sh_flag and sh_fail)
+    uint32_t wbase = 0;
+    if (HYB && tid == 0) *sh_work = 0;
+    // (a wave asks for its next chunk before it works the current one, so the counter's round trip is off the path:
+    // ask() leaves the answer in lane 0, taken() reads it when the chunk is started)
+    auto ask = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (bpl_lane() == 0) v = atomicAdd(sh_work, 1u);
+        return v;
+    };
+    auto taken = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(v) - wbase; };
 #ifdef BPL_PROF
     uint64_t prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #endif
@@ -2828,6 +2846,30 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
             (void)lane;
             if (compared && tid == 0) *sh_flag = 0;
             // ---- update_checks (:150-166), in place: tanh of the bit messages in, check messages out
+            if constexpr (HYB && DC > 0) {
+                if (!by_table) {
+                    // (dealing the chunks whose messages live in the L2 piece between the others, instead of last, made no
+                    // difference beyond the 1 % from run to run)
+                    const uint32_t c_chunks = (m + 63) / 64;
+                    uint32_t vcur = ask();
+                    for (;;) {
+                        const uint32_t ch = taken(vcur);
+                        if (ch >= c_chunks) break;
+                        vcur = ask();
+                        const uint32_t c = ch * 64 + lane;
+                        if (c < m) {
+                            const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
+                            double x[DC], out[DC];
+#pragma unroll
+                            for (int j = 0; j < DC; j++) x[j] = ldm(c * (uint32_t)DC + j);
+                            bp_check_row<DC, BPL_CHECK_BATCH, BPL_SK>(x, sbit ? 0x80000000u : 0u, out);
+#pragma unroll
+                            for (int j = 0; j < DC; j++) stm(c * (uint32_t)DC + j, out[j]);
+                        }
+                    }
+                    wbase += c_chunks + NT / 64;
+                }
+            } else {
             for (uint32_t c = tid; c < m && !by_table; c += NT) {
                 const bool sbit = (sw32[c >> 5] >> (c & 31)) & 1u;
                 if constexpr (DC > 0) {
@@ -2866,6 +2908,8 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                         }
                     }
                 }
+            
+            }
             }
             }
             __syncthreads();
@@ -2876,7 +2920,10 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
             // out; 64 consecutive bits per wave and trip, so a ballot is the decision word
             unsigned long long next_i = 0;
             if (!asked && tid == 0) next_i = atomicAdd(a.queue, 1ull);
-            for (uint32_t b0 = wv * 64; b0 < n; b0 += NT) {
+            const uint32_t b_chunks = (n + 63) / 64;
+            uint32_t vcur = HYB ? ask() : 0u;
+            for (uint32_t b0 = HYB ? taken(vcur) * 64 : wv * 64; b0 < n; b0 = HYB ? taken(vcur) * 64 : b0 + NT) {
+                if (HYB) vcur = ask();
                 const uint32_t b = b0 + lane;
                 bool dec = false, changed = false;
                 if (b < n) {
@@ -2966,6 +3013,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                 const uint64_t mask = __ballot(dec);
                 if (lane == 0) dw[b0 >> 6] = mask;
             }
+            if (HYB) wbase += b_chunks + NT / 64;
             if (!asked) {
                 if (tid == 0) sh_queue[turn ^ 1u] = next_i;
                 asked = true;
