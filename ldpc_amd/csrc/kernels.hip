@@ -1980,6 +1980,10 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // (bp_lds_kernel's use of the scalar-constant forms of bp_math.hpp)
+#ifndef BPL_LISTED_ERRORS
+#define BPL_LISTED_ERRORS 2             // bp_lds_kernel's syndrome phase from a list of the error's set bits: 0 = off, 1 = hybrid form only, 2 = every form with a
+                                        // table iteration (per 2^22 shots, one box: C1 101.9 -> 96.4 ms, CSS example 125.0 -> 122.4 ms, C2 within the noise)
+#endif
 #ifndef BPL_TANH_BATCH
 #define BPL_TANH_BATCH 4                // tanh of a bit's three or four messages: 1 = one by one, 2 = in pairs, else as one batch
 #endif                                  // (CSS example / C1 per 2^22 shots, one box: 129 / 105.7, 137 / 102.7, 127 / 101.9 ms)
@@ -2732,6 +2736,14 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
     // it only grows, a phase's chunks are its values from `wbase` on, and a phase takes exactly chunks + waves of them
     // (every wave's last grab fails), which every wave adds to its own copy of wbase -- no reset, no extra barrier.
     // Each check and bit is computed by the same code whichever wave takes it: results do not depend on the hand-out.
+    // LISTED: the set bits of a shot's error are listed (u16 positions) by the threads that make its words, and the
+    // syndrome phase works the list -- one (error bit, check) pair per thread, one round -- instead of testing every bit
+    // of the word.  The list and its counter borrow the start of the message array, which is dead between a shot's
+    // last iteration and its first bit update (the first iteration comes from the table and writes every message).
+    constexpr bool LISTED = BPL_LISTED_ERRORS && FIRST_BY_TABLE && (HYB || BPL_LISTED_ERRORS > 1);
+    uint32_t *lcnt = (uint32_t *)msg;
+    uint16_t *llist = (uint16_t *)(lcnt + 1);
+    if (LISTED && tid == 0) *lcnt = 0;
     uint32_t *sh_work = q + 67;   // (the spare word after the gap table's 65, sh_flag and sh_fail)
     uint32_t wbase = 0;
     if (HYB && tid == 0) *sh_work = 0;
@@ -2771,6 +2783,10 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                 x = a.source == SRC_DEPOL_X ? xx : zz;
             }
             ew[w] = x;
+            if (LISTED && a.source != SRC_SYNDROMES && x) {
+                uint16_t *lp = llist + atomicAdd(lcnt, (uint32_t)__builtin_popcountll(x));
+                for (uint64_t y = x; y; y &= y - 1) *lp++ = (uint16_t)(w * 64 + (uint32_t)__builtin_ctzll(y));
+            }
             dw[w] = init ? (nb < 64 ? (1ull << nb) - 1 : ~0ull) : 0ull;
         }
         // (syndrome words: the caller's, or zero for the scatter below; the residual starts as syndrome ^ H * (decision
@@ -2792,7 +2808,25 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision: every set
         // bit of the error toggles its checks (few bits are set: E gathers become weight * degree atomics in LDS).  The
         // bit update keeps the residual current from then on.
-        if (a.source != SRC_SYNDROMES)
+        if (LISTED && a.source != SRC_SYNDROMES) {
+            const uint32_t listed = *lcnt;
+            if constexpr (DV > 0) {
+                for (uint32_t t = tid; t < listed * (uint32_t)DV; t += NT) {
+                    const uint32_t c = check_of((uint32_t)llist[t / (uint32_t)DV] * (uint32_t)DV + t % (uint32_t)DV);
+                    atomicXor(&sw32[c >> 5], 1u << (c & 31));
+                    atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                }
+            } else {
+                for (uint32_t t = tid; t < listed; t += NT) {
+                    const uint32_t b = llist[t];
+                    for (uint32_t k = first_edge(b); k < first_edge(b + 1); k++) {
+                        const uint32_t c = check_of(k);
+                        atomicXor(&sw32[c >> 5], 1u << (c & 31));
+                        atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                    }
+                }
+            }
+        } else if (a.source != SRC_SYNDROMES)
             for (uint32_t b = tid; b < n; b += NT)
                 if ((ew32[b >> 5] >> (b & 31)) & 1u) {
                     const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), k1 = DV > 0 ? k0 + (uint32_t)DV : first_edge(b + 1);
@@ -3037,6 +3071,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
         BPL_FRESH();
+        if (LISTED && tid == 0) *lcnt = 0;   // (the messages are dead: the next shot's error list starts here)
         if (tid == 0 && !asked) sh_queue[turn ^ 1u] = atomicAdd(a.queue, 1ull);   // (a shot that stopped before its first update)
         const bool det = !conv;
         bool fail = false;
