@@ -1980,6 +1980,9 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // (bp_lds_kernel's use of the scalar-constant forms of bp_math.hpp)
+#ifndef BPL_WORDS_BY_BLOCK
+#define BPL_WORDS_BY_BLOCK 1            // bp_lds_kernel's BSC words through bsc_block (1) or bsc_word (0): C1 96.1 -> 95.3 ms per 2^22 shots
+#endif
 #ifndef BPL_LISTED_ERRORS
 #define BPL_LISTED_ERRORS 2             // bp_lds_kernel's syndrome phase from a list of the error's set bits: 0 = off, 1 = hybrid form only, 2 = every form with a
                                         // table iteration (per 2^22 shots, one box: C1 101.9 -> 96.4 ms, CSS example 125.0 -> 122.4 ms, C2 within the noise)
@@ -2773,8 +2776,22 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         for (uint32_t w = tid; w < Wn; w += NT) {
             const uint32_t nb = bits_in_word(n, w);
             uint64_t x = 0;
-            if (a.source == SRC_BSC) x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
-            else if (a.source == SRC_WORDS) {
+            if (a.source == SRC_BSC) {
+#if BPL_WORDS_BY_BLOCK
+                // (the word block by block with the four gaps of a block looked up side by side and without branches:
+                // the same stream and the same word as bsc_word; a look-up that the float estimate misses -- or that
+                // reads the flag word behind the table at j = 64 -- takes the exact search)
+                if (!a.gap.p_is_zero) {
+                    uint32_t pos = 0;
+                    for (uint32_t blk = 0; !bsc_block(q, a.gap.inv_log2q, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)shot, (uint32_t)(shot >> 32), w,
+                                                      blk, nb, x, pos);
+                         blk++) {
+                    }
+                }
+#else
+                x = bsc_word(q, a.gap.inv_log2q, a.gap.p_is_zero, a.seed, shot, w, nb);
+#endif
+            } else if (a.source == SRC_WORDS) {
                 x = a.words_in[myi * Wn + w];
                 if (nb < 64) x &= (1ull << nb) - 1;
             } else if (a.source != SRC_SYNDROMES) {
