@@ -1980,6 +1980,9 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
 // ---------------------------------------------------------------------------
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // (bp_lds_kernel's use of the scalar-constant forms of bp_math.hpp)
+#ifndef BPL_TPACK_AHEAD
+#define BPL_TPACK_AHEAD 1                // bp_lds_kernel's bit update: a bit's packed graph words loaded one chunk ahead (bits of one fixed degree)
+#endif
 #ifndef BPL_WORDS_BY_BLOCK
 #define BPL_WORDS_BY_BLOCK 1            // bp_lds_kernel's BSC words through bsc_block (1) or bsc_word (0): C1 96.1 -> 95.3 ms per 2^22 shots
 #endif
@@ -2972,9 +2975,31 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
             unsigned long long next_i = 0;
             if (!asked && tid == 0) next_i = atomicAdd(a.queue, 1ull);
             const uint32_t b_chunks = (n + 63) / 64;
-            uint32_t vcur = HYB ? ask() : 0u;
-            for (uint32_t b0 = HYB ? taken(vcur) * 64 : wv * 64; b0 < n; b0 = HYB ? taken(vcur) * 64 : b0 + NT) {
-                if (HYB) vcur = ask();
+            // AHEAD (bits of one fixed degree): a bit's packed graph words (edge | check << 16, one per check) are asked
+            // for one chunk ahead, from global memory whether or not LDS holds copies of the graph: the loads of chunk
+            // i + 1 travel while chunk i is worked, instead of a memory (or LDS) round trip at the head of every chunk.
+            // HYB keeps two hand-outs in flight for that (the chunk after next is asked for while the next one's words
+            // are loaded): every wave's last TWO grabs fail, which is what wbase counts.
+            constexpr bool AHEAD = BPL_TPACK_AHEAD && DV > 0;
+            constexpr uint32_t TPN = DV > 0 ? (uint32_t)DV : 1u;
+            uint32_t tp[TPN], tpn[TPN];
+            auto load_tp = [&](uint32_t at, uint32_t (&t)[TPN]) {
+#pragma unroll
+                for (uint32_t k = 0; k < TPN; k++) t[k] = at + lane < n ? g.t_pack[(at + lane) * TPN + k] : 0u;
+            };
+            uint32_t vcur = 0, b0 = wv * 64, b0n = 0;
+            if (HYB) {
+                const uint32_t v1 = ask();
+                vcur = ask();
+                b0 = taken(v1) * 64;
+            }
+            if (AHEAD) load_tp(b0, tp);
+            for (; b0 < n; b0 = b0n) {
+                if (HYB) {
+                    b0n = taken(vcur) * 64;
+                    vcur = ask();
+                } else b0n = b0 + NT;
+                if (AHEAD) load_tp(b0n, tpn);
                 const uint32_t b = b0 + lane;
                 bool dec = false, changed = false;
                 if (b < n) {
@@ -2985,7 +3010,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                         uint32_t pat = 0, pk[RD];
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
-                            if (DV > 0 || k < dv) pk[k] = slot_of(k0 + k);
+                            if (DV > 0 || k < dv) pk[k] = AHEAD ? tp[k < TPN ? k : 0] : slot_of(k0 + k);
 #pragma unroll
                         for (uint32_t k = 0; k < RD; k++)
                             if (DV > 0 || k < dv) {
@@ -3003,7 +3028,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                         for (uint32_t k = 0; k < RD; k++) {
                             v[k] = 0.0;
                             if (DV > 0 || k < dv) {
-                                ed[k] = edge_of(k0 + k);
+                                ed[k] = AHEAD ? tp[k < TPN ? k : 0] & 0xFFFFu : edge_of(k0 + k);
                                 v[k] = ldm(ed[k]);
                             }
                         }
@@ -3055,16 +3080,29 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                     }
                     dec = post < 0.0;
                     changed = dec != (((dw32[b >> 5] >> (b & 31)) & 1u) != 0);
-                    if (changed)   // (few bits after the first iteration)
-                        for (uint32_t k = 0; k < dv; k++) {
-                            const uint32_t c = check_of(k0 + k);
-                            atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                    if (changed) {   // (few bits after the first iteration)
+                        if constexpr (AHEAD) {
+#pragma unroll
+                            for (uint32_t k = 0; k < TPN; k++) {
+                                const uint32_t c = tp[k] >> 16;
+                                atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                            }
+                        } else {
+                            for (uint32_t k = 0; k < dv; k++) {
+                                const uint32_t c = check_of(k0 + k);
+                                atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                            }
                         }
+                    }
                 }
                 const uint64_t mask = __ballot(dec);
                 if (lane == 0) dw[b0 >> 6] = mask;
+                if (AHEAD) {
+#pragma unroll
+                    for (uint32_t k = 0; k < TPN; k++) tp[k] = tpn[k];
+                }
             }
-            if (HYB) wbase += b_chunks + NT / 64;
+            if (HYB) wbase += b_chunks + 2 * (NT / 64);
             if (!asked) {
                 if (tid == 0) sh_queue[turn ^ 1u] = next_i;
                 asked = true;
