@@ -159,7 +159,7 @@ struct ldpc_code {
     mutable std::mutex mu;
     mutable bool uploaded = false;
     mutable int device = -1;   // the GPU that holds the graph (and the owning decoder's buffers)
-    mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge, d_tpack;
+    mutable DeviceBuffer d_hptr, d_hidx, d_tptr, d_tidx, d_tedge, d_tpack, d_tpack4;
     mutable DeviceGraph dg{};
     // staging for the single-vector entry points (kept across calls: a trait-level call is one shot, and an
     // allocation and a free per call would cost more than its kernel); io_mu is held for the whole call
@@ -199,11 +199,19 @@ struct ldpc_code {
         HIP_TRY(up(d_tidx, t.idx));
         HIP_TRY(up(d_tedge, tedge));
         dg.t_pack = nullptr;
+        dg.t_pack4 = nullptr;
         if (t.nnz() && t.nnz() < 65536 && h.nrows() < 65536) {   // (small codes: bp_lds_kernel reads edge and check of a slot as one word)
             std::vector<uint32_t> pack(t.nnz());
             for (size_t k = 0; k < pack.size(); k++) pack[k] = tedge[k] | (t.idx[k] << 16);
             HIP_TRY(up(d_tpack, pack));
             dg.t_pack = d_tpack.as<uint32_t>();
+            if (t.max_row_len() <= 4) {   // (bits of mixed degree up to four: a bit's words as one 16-byte row, bp_lds_kernel loads them a chunk ahead)
+                std::vector<uint32_t> pack4((size_t)h.ncols * 4, 0xFFFFFFFFu);
+                for (uint32_t b = 0; b < h.ncols; b++)
+                    for (uint32_t k = t.ptr[b]; k < t.ptr[b + 1]; k++) pack4[(size_t)b * 4 + (k - t.ptr[b])] = pack[k];
+                HIP_TRY(up(d_tpack4, pack4));
+                dg.t_pack4 = d_tpack4.as<uint4>();
+            }
         }
         dg.n = h.ncols;
         dg.m = h.nrows();

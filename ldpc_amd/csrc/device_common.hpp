@@ -21,6 +21,7 @@ struct DeviceGraph {
     const uint32_t *t_idx;  // [E]    slot  -> check (ascending inside a bit)
     const uint32_t *t_edge; // [E]    slot  -> edge index in check-major order
     const uint32_t *t_pack; // [E]    slot  -> edge | check << 16 (one load for both; null unless E and m are below 65536)
+    const uint4 *t_pack4;   // [n]    bit   -> its (at most four) t_pack words, unused ones 0xFFFFFFFF (null unless t_pack exists and max_dv <= 4)
 };
 
 // Geometric gap table of a channel: P(gap >= j) = q[j] / 2^32, j = 1..64.

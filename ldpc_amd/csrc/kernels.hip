@@ -1981,7 +1981,8 @@ __global__ __launch_bounds__((NF + NH) * 64) void flip4_kernel(DeviceGraph g, Nb
 constexpr uint32_t REG_DEG = 8;   // degrees up to this keep a row in registers
 // (bp_lds_kernel's use of the scalar-constant forms of bp_math.hpp)
 #ifndef BPL_TPACK_AHEAD
-#define BPL_TPACK_AHEAD 1                // bp_lds_kernel's bit update: a bit's packed graph words loaded one chunk ahead (bits of one fixed degree)
+#define BPL_TPACK_AHEAD 2                // bp_lds_kernel's bit update: a bit's packed graph words loaded one chunk ahead: 1 = bits of one fixed degree
+                                        // (per 2^22 shots C2 1921 -> 1813 ms, C1 95.1 -> 89.0 ms), 2 = also mixed degrees up to four (CSS example 122.4 -> 117.5 ms)
 #endif
 #ifndef BPL_WORDS_BY_BLOCK
 #define BPL_WORDS_BY_BLOCK 1            // bp_lds_kernel's BSC words through bsc_block (1) or bsc_word (0): C1 96.1 -> 95.3 ms per 2^22 shots
@@ -2980,12 +2981,20 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
             // i + 1 travel while chunk i is worked, instead of a memory (or LDS) round trip at the head of every chunk.
             // HYB keeps two hand-outs in flight for that (the chunk after next is asked for while the next one's words
             // are loaded): every wave's last TWO grabs fail, which is what wbase counts.
-            constexpr bool AHEAD = BPL_TPACK_AHEAD && DV > 0;
-            constexpr uint32_t TPN = DV > 0 ? (uint32_t)DV : 1u;
+            // (bits of mixed degree up to four, DV < 0: the same from the rows of t_pack4, 16 bytes per bit; the bit's
+            // degree is the number of its words that are not the filler)
+            constexpr bool AHEAD = (BPL_TPACK_AHEAD && DV > 0) || (BPL_TPACK_AHEAD > 1 && DV == -4);
+            constexpr uint32_t TPN = DV > 0 ? (uint32_t)DV : DV == -4 ? 4u : 1u;
             uint32_t tp[TPN], tpn[TPN];
             auto load_tp = [&](uint32_t at, uint32_t (&t)[TPN]) {
+                if constexpr (DV > 0) {
 #pragma unroll
-                for (uint32_t k = 0; k < TPN; k++) t[k] = at + lane < n ? g.t_pack[(at + lane) * TPN + k] : 0u;
+                    for (uint32_t k = 0; k < TPN; k++) t[k] = at + lane < n ? g.t_pack[(at + lane) * TPN + k] : 0u;
+                } else if constexpr (DV == -4) {
+                    uint4 r = make_uint4(NONE, NONE, NONE, NONE);
+                    if (at + lane < n) r = g.t_pack4[at + lane];
+                    t[0] = r.x; t[1] = r.y; t[2] = r.z; t[3] = r.w;
+                }
             };
             uint32_t vcur = 0, b0 = wv * 64, b0n = 0;
             if (HYB) {
@@ -3004,7 +3013,17 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                 bool dec = false, changed = false;
                 if (b < n) {
                     constexpr uint32_t RD = DV > 0 ? (uint32_t)DV : DV < 0 ? (uint32_t)(-DV) : REG_DEG;
-                    const uint32_t k0 = DV > 0 ? b * (uint32_t)DV : first_edge(b), dv = DV > 0 ? (uint32_t)DV : first_edge(b + 1) - k0;
+                    uint32_t k0 = 0, dv = 0;
+                    if constexpr (DV > 0) {
+                        k0 = b * (uint32_t)DV;
+                        dv = (uint32_t)DV;
+                    } else if constexpr (AHEAD) {
+#pragma unroll
+                        for (uint32_t k = 0; k < TPN; k++) dv += tp[k] != NONE ? 1u : 0u;
+                    } else {
+                        k0 = first_edge(b);
+                        dv = first_edge(b + 1) - k0;
+                    }
                     double sum = 0.0, post = prior;
                     if (by_table) {
                         uint32_t pat = 0, pk[RD];
@@ -3083,10 +3102,11 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                     if (changed) {   // (few bits after the first iteration)
                         if constexpr (AHEAD) {
 #pragma unroll
-                            for (uint32_t k = 0; k < TPN; k++) {
-                                const uint32_t c = tp[k] >> 16;
-                                atomicXor(&rw32[c >> 5], 1u << (c & 31));
-                            }
+                            for (uint32_t k = 0; k < TPN; k++)
+                                if (DV > 0 || k < dv) {
+                                    const uint32_t c = tp[k] >> 16;
+                                    atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                                }
                         } else {
                             for (uint32_t k = 0; k < dv; k++) {
                                 const uint32_t c = check_of(k0 + k);
