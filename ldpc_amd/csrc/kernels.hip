@@ -2614,7 +2614,10 @@ __host__ __device__ inline size_t bp_lds_words(const DeviceGraph &g, uint32_t co
                                                uint32_t e_lds = 0xFFFFFFFFu)   // (edges whose messages live in LDS: all, but for the hybrid form)
 {
     const size_t Wn = (g.n + 63) / 64, Wm = (g.m + 63) / 64;
-    const size_t u16s = (copies >= 1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (copies >= 2 ? (size_t)g.E : 0) +
+    // (copies == 4: the logical generators' rows alone -- the kernels that load a bit's packed graph words a chunk ahead
+    // from global memory have no use for the graph in LDS)
+    const bool graph1 = copies >= 1 && copies <= 3, graph2 = copies >= 2 && copies <= 3;
+    const size_t u16s = (graph1 ? (size_t)g.E + (mixed_bits ? g.n + 1 : 0) : 0) + (graph2 ? (size_t)g.E : 0) +
                         (copies >= 3 ? (size_t)l_rows + 1 + l_nnz : 0);
     return (size_t)std::min(g.E, e_lds) + 2 * Wn + 2 * Wm + 34 + 2 + 5 + BPL_TABLE_WORDS + (u16s + 3) / 4;
 }
@@ -2661,8 +2664,8 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
     unsigned long long *cnt = sh_queue + 2;   // shots, failures, runs that did not converge, iterations, iterations of arithmetic
     double *tab_t = (double *)(cnt + 5), *tab_p = tab_t + 4 * 16 * 4;
     uint16_t *tedge = (uint16_t *)(tab_p + 5 * 16), *tptr = tedge + E, *tidx = tptr + (DV > 0 ? 0 : n + 1);
-    uint16_t *lptr = tidx + (copies >= 2 ? E : 0), *lidx = lptr + a.l_rows + 1;
-    const bool c_edges = copies >= 1, c_checks = copies >= 2, c_logicals = copies >= 3;
+    const bool c_edges = copies >= 1 && copies <= 3, c_checks = copies >= 2 && copies <= 3, c_logicals = copies >= 3;   // (4: logical rows alone)
+    uint16_t *lptr = copies == 4 ? tedge : tidx + (c_checks ? E : 0), *lidx = lptr + a.l_rows + 1;
     auto edge_of = [&](uint32_t k) -> uint32_t { return c_edges ? (uint32_t)tedge[k] : g.t_pack[k] & 0xFFFFu; };
     auto first_edge = [&](uint32_t b) -> uint32_t { return c_edges ? (uint32_t)tptr[b] : g.t_ptr[b]; };
     auto check_of = [&](uint32_t k) -> uint32_t { return c_checks ? (uint32_t)tidx[k] : g.t_pack[k] >> 16; };
@@ -2840,10 +2843,22 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
             } else {
                 for (uint32_t t = tid; t < listed; t += NT) {
                     const uint32_t b = llist[t];
-                    for (uint32_t k = first_edge(b); k < first_edge(b + 1); k++) {
-                        const uint32_t c = check_of(k);
-                        atomicXor(&sw32[c >> 5], 1u << (c & 31));
-                        atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                    if constexpr (DV == -4 && BPL_TPACK_AHEAD > 1) {   // (the bit's checks in one 16-byte row)
+                        const uint4 r = g.t_pack4[b];
+                        const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (w4[k] != NONE) {
+                                const uint32_t c = w4[k] >> 16;
+                                atomicXor(&sw32[c >> 5], 1u << (c & 31));
+                                atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                            }
+                    } else {
+                        for (uint32_t k = first_edge(b); k < first_edge(b + 1); k++) {
+                            const uint32_t c = check_of(k);
+                            atomicXor(&sw32[c >> 5], 1u << (c & 31));
+                            atomicXor(&rw32[c >> 5], 1u << (c & 31));
+                        }
                     }
                 }
             }
@@ -4111,8 +4126,11 @@ static BpLdsShape bp_lds_shape(const DeviceGraph &g, int dc, int dv, uint32_t l_
     const bool mixed = !(dv == 3);
     BpLdsShape best{0, 0, BPL_THREADS, 0};
     // (the most workgroups, then the most copies; the logical rows only when there are some and u16 holds their offsets)
-    const uint32_t most = l_rows && l_nnz < 65536 ? 3 : 2;
-    for (uint32_t copies = 0; copies <= most; copies++) {
+    // (the forms that load a bit's packed graph words a chunk ahead -- every bit degree but "any" -- read nothing of the
+    // graph from LDS: for them the choice is between no copy and the logical rows alone, level 4)
+    const bool ahead = BPL_TPACK_AHEAD > 1 ? (dv == 3 || dv == -4 || (dv >= 1 && dv <= 4)) : BPL_TPACK_AHEAD == 1 && dv == 3;
+    const uint32_t most = ahead ? (l_rows && l_nnz < 65536 ? 4 : 0) : l_rows && l_nnz < 65536 ? 3 : 2;
+    for (uint32_t copies = 0; copies <= most; copies += ahead ? 4 : 1) {
         const size_t lds = bp_lds_words(g, copies, mixed, l_rows, l_nnz) * 8;
         if (lds > 160 * 1024) break;
         int per_cu = 0;
