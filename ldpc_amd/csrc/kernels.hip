@@ -372,6 +372,9 @@ __host__ __device__ inline size_t flip_big_words(uint32_t n, uint32_t m)
     return Wm + 2 * Wn + W1 + W2 + 8;
 }
 
+#ifndef FLIP_BIG_WIDE
+#define FLIP_BIG_WIDE 1
+#endif
 __global__ __launch_bounds__(256) void flip_big_kernel(DeviceGraph g, FlipArgs a, uint64_t *big)
 {
     __shared__ uint32_t q[65];
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(256) void flip_big_kernel(DeviceGraph g, FlipArgs a
     uint64_t *S = big + gw * flip_big_words(g.n, g.m), *F = S + Wm, *O = F + Wn, *FS = O + Wn, *FSS = FS + W1;
     const uint32_t state_words = Wm + 2 * Wn + W1 + W2;
     uint64_t c_shots = 0, c_fail = 0, c_det = 0, c_undet = 0, c_flips = 0;
+    const bool small = g.max_dv <= 8 && g.max_dc <= 8 && FLIP_BIG_WIDE;   // (wave-uniform: the flip step's parallel form)
 
     // unsatisfied checks of bit b > deg / 2 (flip.rs:41)
     auto flippable = [&](uint32_t b) -> bool {
@@ -468,6 +472,40 @@ __global__ __launch_bounds__(256) void flip_big_kernel(DeviceGraph g, FlipArgs a
             nflips++;
             const uint32_t k0 = g.t_ptr[b], deg = g.t_ptr[b + 1] - k0;
             if (lane == 0) xorbit_g(O, b);                                 // flip.rs:30
+            if (small) {
+                // Degrees up to eight (round 3): the neighbourhood of b is refreshed in one go, lane = (check of b, bit of
+                // that check), and a neighbour's checks and syndrome words are asked for together -- a dozen dependent
+                // memory round trips per flip where the general form below takes about forty (three checks one after
+                // the other, each neighbour's checks one after the other).  A neighbour met through two checks is
+                // refreshed twice, to the same value.
+                uint32_t e0_l = 0, dc_l = 0;
+                if (lane < deg) {
+                    const uint32_t c = g.t_idx[k0 + lane];
+                    xorbit_g(S, c);                                        // flip.rs:29
+                    e0_l = g.h_ptr[c];
+                    dc_l = g.h_ptr[c + 1] - e0_l;
+                }
+                wave_sync();
+                const uint32_t i2 = lane >> 3, j = lane & 7;
+                const uint32_t e0 = (uint32_t)__shfl((int)e0_l, (int)i2, 64), dc = (uint32_t)__shfl((int)dc_l, (int)i2, 64);
+                if (i2 < deg && j < dc) {
+                    const uint32_t bb = g.h_idx[e0 + j];
+                    const uint32_t kb0 = g.t_ptr[bb], degb = g.t_ptr[bb + 1] - kb0;
+                    uint32_t ck[8];
+                    uint64_t sw[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) ck[k] = k < degb ? g.t_idx[kb0 + k] : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) sw[k] = k < degb ? ld64(S + (ck[k] >> 6)) : 0ull;
+                    uint32_t unsat = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) unsat += (uint32_t)(sw[k] >> (ck[k] & 63)) & (k < degb ? 1u : 0u);
+                    if (unsat > degb / 2) set_f(bb);
+                    else clrbit_g(F, bb);
+                }
+                wave_sync();
+                continue;
+            }
             for (uint32_t kk = lane; kk < deg; kk += 64) xorbit_g(S, g.t_idx[k0 + kk]);   // flip.rs:29
             wave_sync();
             // refresh F for every bit that shares a check with b (b itself included)
