@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ldpc_amd
+if os.environ.get("AB_LIB"):   # a variant library (scripts/build_variant.sh)
+    ldpc_amd.LIB_PATH = os.environ["AB_LIB"]
 from ldpc_amd import FlipDecoder, LinearCode
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.02
 shots = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
