@@ -2791,7 +2791,10 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
     constexpr bool LISTED = BPL_LISTED_ERRORS && FIRST_BY_TABLE && (HYB || BPL_LISTED_ERRORS > 1);
     uint32_t *lcnt = (uint32_t *)msg;
     uint16_t *llist = (uint16_t *)(lcnt + 1);
-    if (LISTED && tid == 0) *lcnt = 0;
+    // (a code with hardly any edges -- most bits in no check -- has a message array shorter than a full list: it keeps
+    // the scan of the word)
+    const bool listed = LISTED && (size_t)EL * 8 >= 4 + 2 * (size_t)n;
+    if (listed && tid == 0) *lcnt = 0;
     uint32_t *sh_work = q + 67;   // (the spare word after the gap table's 65, sh_flag and sh_fail)
     uint32_t wbase = 0;
     if (HYB && tid == 0) *sh_work = 0;
@@ -2845,7 +2848,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
                 x = a.source == SRC_DEPOL_X ? xx : zz;
             }
             ew[w] = x;
-            if (LISTED && a.source != SRC_SYNDROMES && x) {
+            if (listed && a.source != SRC_SYNDROMES && x) {
                 uint16_t *lp = llist + atomicAdd(lcnt, (uint32_t)__builtin_popcountll(x));
                 for (uint64_t y = x; y; y &= y - 1) *lp++ = (uint16_t)(w * 64 + (uint32_t)__builtin_ctzll(y));
             }
@@ -2870,16 +2873,16 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         // ---- syndrome H e (linear_code/mod.rs:393-405) and the stop test's residual syndrome ^ H * decision: every set
         // bit of the error toggles its checks (few bits are set: E gathers become weight * degree atomics in LDS).  The
         // bit update keeps the residual current from then on.
-        if (LISTED && a.source != SRC_SYNDROMES) {
-            const uint32_t listed = *lcnt;
+        if (listed && a.source != SRC_SYNDROMES) {
+            const uint32_t n_listed = *lcnt;
             if constexpr (DV > 0) {
-                for (uint32_t t = tid; t < listed * (uint32_t)DV; t += NT) {
+                for (uint32_t t = tid; t < n_listed * (uint32_t)DV; t += NT) {
                     const uint32_t c = check_of((uint32_t)llist[t / (uint32_t)DV] * (uint32_t)DV + t % (uint32_t)DV);
                     atomicXor(&sw32[c >> 5], 1u << (c & 31));
                     atomicXor(&rw32[c >> 5], 1u << (c & 31));
                 }
             } else {
-                for (uint32_t t = tid; t < listed; t += NT) {
+                for (uint32_t t = tid; t < n_listed; t += NT) {
                     const uint32_t b = llist[t];
                     if constexpr (DV == -4 && BPL_TPACK_AHEAD > 1) {   // (the bit's checks in one 16-byte row)
                         const uint4 r = g.t_pack4[b];
@@ -3199,7 +3202,7 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         }
         // ---- the shot has stopped: failure test, outputs (css/mod.rs:225-252 for the logical test)
         BPL_FRESH();
-        if (LISTED && tid == 0) *lcnt = 0;   // (the messages are dead: the next shot's error list starts here)
+        if (listed && tid == 0) *lcnt = 0;   // (the messages are dead: the next shot's error list starts here)
         if (tid == 0 && !asked) sh_queue[turn ^ 1u] = atomicAdd(a.queue, 1ull);   // (a shot that stopped before its first update)
         const bool det = !conv;
         bool fail = false;

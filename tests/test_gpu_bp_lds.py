@@ -310,3 +310,30 @@ def test_lds_checks_of_any_degree(monkeypatch):
 
         out = _forms(monkeypatch, run)
         assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"]), n
+
+
+def test_lds_code_with_hardly_any_edges(monkeypatch):
+    """Most bits in no check: the message array (8 bytes per edge) is shorter than a list of every error position, so
+    the set-up keeps the scan of the word (the list borrows that array; round 3).  Checks of degree 3 and bits of
+    degree at most 2 take the form with the first-iteration table, the one that lists: all forms bit for bit, and the
+    oracle's decisions."""
+    n = 640
+    rows = [[3, 200, 411], [3, 17, 599], [64, 200, 630]]
+    code = LinearCode.from_parity_check_matrix(n, rows)
+    shots = 300
+    words = np.stack([orc.sample_bsc_words(11, i, 0.3, n) for i in range(shots)]).reshape(shots, nwords(n))
+
+    def run():
+        dec = BpDecoder(code, 0.3, 10)
+        do = dev_u64(words.shape)
+        dec.decode_batch(shots, to_dev_u64(words), do)
+        cnt = dec.mc_run(0.3, 4, 0, 500)
+        return host_u64(do), cnt
+
+    out = _forms(monkeypatch, run)
+    assert _same(out["lds"], out["persistent"]) and _same(out["lds"], out["stream"])
+    oc = oracle_code(code)
+    want = np.stack([oc.bp_decode_words(0.3, 10, words[i])[0] for i in range(shots)])
+    assert (out["lds"][0] == want).all(axis=1).mean() >= 0.9999
+    cnt = oc.mc_bp(0.3, 10, 4, 0, 500)
+    assert [int(x) for x in out["lds"][1][:5]] == [int(x) for x in cnt[:5]]
