@@ -2741,8 +2741,8 @@ __global__ __launch_bounds__(WIDE ? BPL_MAX_THREADS : BPL_THREADS, HYB ? BPL_HYB
         for (int j = 0; j < DC; j++) x[j] = t_prior;
         bp_check_row<DC, BPL_CHECK_BATCH, BPL_SK>(x, 0u, out);
         const double v0 = out[0];
-        if (tid < 5 * 16) {
-            const uint32_t d = tid >> 4, pat = tid & 15;
+        for (uint32_t t5 = tid; t5 < 5 * 16; t5 += NT) {   // (a workgroup may be one wave: LDPC_HIP_BP_LDS_THREADS=64)
+            const uint32_t d = t5 >> 4, pat = t5 & 15;
             double v[4], sum = 0.0, post = prior;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) v[k] = (pat >> k) & 1u ? -v0 : v0;

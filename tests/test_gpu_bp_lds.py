@@ -129,10 +129,24 @@ def test_lds_workgroup_sizes_change_nothing(monkeypatch):
         flags = dev_u8((3000,))
         cnt = BpDecoder(code, 0.03, 25).mc_run(0.03, 8, 0, 3000, flags)
         res.append((cnt, flags.cpu().numpy()))
+    assert all(_same(res[0], r) for r in res[1:])
+    # bits of four checks: the first-iteration table has 80 entries, more than a one-wave workgroup has threads (a
+    # workgroup of 64 threads left the last sixteen unbuilt until round 3)
+    code = LinearCode.random_regular_code(600, 400, 4, 6, seed=3)
+    res = []
+    for threads in ("64", "128", "256"):
+        monkeypatch.setenv("LDPC_HIP_BP_LDS_THREADS", threads)
+        ldpc_amd.reload_switches()
+        flags = dev_u8((3000,))
+        cnt = BpDecoder(code, 0.03, 25).mc_run(0.03, 8, 0, 3000, flags)
+        assert ldpc_amd.last_kernel_name().startswith("bp_lds_kernel")
+        res.append((cnt, flags.cpu().numpy()))
     monkeypatch.delenv("LDPC_HIP_BP_LDS_THREADS")
     monkeypatch.delenv("LDPC_HIP_BP_PATH")
     ldpc_amd.reload_switches()
     assert all(_same(res[0], r) for r in res[1:])
+    want = oracle_code(code).mc_bp(0.03, 25, 8, 0, 3000, nthreads=8)
+    assert [int(x) for x in res[0][0][:5]] == [int(x) for x in want[:5]]
 
 
 def test_lds_hybrid_form_on_the_headline_code(monkeypatch):
